@@ -1,0 +1,170 @@
+/*
+ * sph_hip.h -- C ABI of libsph_hip.so: the MI355X (gfx950) WCSPH step.
+ *
+ * The reference (erizmr/SPH_Taichi) has no FFI layer: its device code is
+ * Taichi @ti.kernel Python.  This header is the boundary a maintainer binds
+ * (ctypes) to replace each kernel of the hot path.  Every
+ * entry point names the reference kernel it replaces (paths relative to the
+ * reference root).  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * Contract
+ *  - One opaque context per GPU.  The context owns every device buffer and
+ *    (unless sph_set_stream is used) one HIP stream.  A context is driven by
+ *    one host thread at a time.
+ *  - Compute entry points ENQUEUE on the context's stream and return;
+ *    sph_download / sph_sync / sph_get_timings / sph_get_counts synchronise.
+ *  - Every function returns 0 on success, a negative SPH_E_* code or a positive
+ *    hipError_t otherwise; sph_last_error(ctx) gives the message.  Nothing
+ *    throws.
+ *  - Array layout at the boundary is the reference's (particle_system.py:
+ *    101-113): vectors [N,3] f32 row-major, scalars [N] f32, ints [N] i32,
+ *    color [N,3] i32.  The SoA/float4 packing inside is private.
+ *  - Particle order: after sph_counting_sort / sph_step every array is in the
+ *    reference's cell-sorted order with the STABLE intra-cell order a serial
+ *    run of particle_system.py:322-330 produces.
+ */
+#ifndef SPH_HIP_H
+#define SPH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPH_ABI_VERSION 1
+
+typedef struct SphContext SphContext;
+
+/* Scalars of ParticleSystem.__init__ (particle_system.py:17-46), SPHBase.__init__
+ * (sph_base.py:8-21) and WCSPHSolver.__init__ (WCSPH.py:6-16).  Constants that
+ * the reference folds in Python f64 before they enter a kernel (k_w, k_dw,
+ * visc_d_nu, visc_eps) are passed already folded, as f32. */
+typedef struct SphParams {
+    int32_t n_particles;        /* particle_max_num              particle_system.py:83 */
+    int32_t capacity;           /* >= n_particles; slack for halo/migration (multi-GPU) */
+    int32_t grid_num[3];        /* LOCAL grid dims               particle_system.py:44 */
+    int32_t cell_origin[3];     /* global cell coord of local cell (0,0,0); 0 on one GPU */
+    int32_t n_objects;          /* len(rigid_rest_cm)            particle_system.py:93 */
+    float grid_size;            /* = support_radius              particle_system.py:43 */
+    float support_radius;       /* 4 r                           particle_system.py:37 */
+    float particle_diameter;    /* 2 r                           particle_system.py:36 */
+    float m_V0;                 /* 0.8 d^3                       particle_system.py:38 */
+    float density_0;            /* sph_base.py:18 */
+    float stiffness;            /* WCSPH.py:13 */
+    float exponent;             /* WCSPH.py:10 */
+    float viscosity;            /* sph_base.py:15 */
+    float surface_tension;      /* WCSPH.py:15 */
+    float dt;                   /* WCSPH.py:16 */
+    float g[3];                 /* sph_base.py:13 */
+    float domain_size[3];       /* particle_system.py:22 */
+    float padding;              /* particle_system.py:46 */
+    float wall_hi[3];           /* domain_size - padding, folded in f64 (sph_base.py:153-170) */
+    float k_w;                  /* 8/pi/h^3          sph_base.py:33-35 */
+    float k_dw;                 /* 6*8/pi/h^3        sph_base.py:57 */
+    float visc_d_nu;            /* 2(dim+2)*viscosity WCSPH.py:104,112 */
+    float visc_eps;             /* 0.01 h^2          WCSPH.py:113 */
+} SphParams;
+
+/* Per-particle arrays of particle_system.py:101-113, 138 (+ the grid counter
+ * array :96 and a persistent particle id that the reference does not have). */
+enum SphField {
+    SPH_F_OBJECT_ID = 0,          /* i32 [N]   */
+    SPH_F_X = 1,                  /* f32 [N,3] */
+    SPH_F_X_0 = 2,                /* f32 [N,3] */
+    SPH_F_V = 3,                  /* f32 [N,3] */
+    SPH_F_ACCELERATION = 4,       /* f32 [N,3] */
+    SPH_F_M_V = 5,                /* f32 [N]   */
+    SPH_F_M = 6,                  /* f32 [N]   */
+    SPH_F_DENSITY = 7,            /* f32 [N]   */
+    SPH_F_PRESSURE = 8,           /* f32 [N]   */
+    SPH_F_MATERIAL = 9,           /* i32 [N]   */
+    SPH_F_COLOR = 10,             /* i32 [N,3] */
+    SPH_F_IS_DYNAMIC = 11,        /* i32 [N]   */
+    SPH_F_GRID_IDS = 12,          /* i32 [N]   particle_system.py:138 (download only) */
+    SPH_F_GRID_PARTICLES_NUM = 13,/* i32 [G]   particle_system.py:96  (download only) */
+    SPH_F_PID = 14,               /* i32 [N]   persistent id = index at upload time (download only) */
+    SPH_F_RIGID_REST_CM = 15,     /* f32 [n_objects,3]  particle_system.py:93 */
+    SPH_F_COUNT_ = 16
+};
+
+enum SphError {
+    SPH_OK = 0,
+    SPH_E_INVALID = -1,      /* bad argument / size mismatch */
+    SPH_E_NO_DEVICE = -2,    /* no HIP device / wrong architecture */
+    SPH_E_NOMEM = -3,
+    SPH_E_STATE = -4         /* call order violated (e.g. sort before grid ids) */
+};
+
+/* Neighbour-gather implementation: 0 = per-particle cell walk through L1/L2,
+ * 1 = LDS-staged cell bricks (default). */
+enum SphOption {
+    SPH_OPT_GATHER_IMPL = 0,
+    SPH_OPT_TIMING = 1,        /* 1 = record per-phase HIP events inside sph_step */
+    SPH_OPT_FUSED_STEP = 2,    /* 1 (default) = sph_step uses the fused density+EOS / force kernels */
+    SPH_OPT_BRICK_SHAPE = 3    /* index into the compiled brick-shape table */
+};
+
+/* ms accumulated by sph_step since the last sph_reset_timings (HIP events on
+ * the context's stream).  sort = K1+K2+K3 (initialize_particle_system),
+ * neighbour = K4+K5 (boundary volume + density/EOS), force = K6+K7,
+ * integrate = K8+K9+K10, halo = multi-GPU exchange packing. */
+typedef struct SphTimings {
+    double sort_ms, neighbour_ms, force_ms, integrate_ms, halo_ms, total_ms;
+    int64_t steps;
+} SphTimings;
+
+int32_t sph_abi_version(void);
+int32_t sph_device_count(void);
+
+/* ParticleSystem.__init__ field allocation (particle_system.py:91-145). `stream`
+ * may be NULL (the context creates its own) or a hipStream_t to enqueue on. */
+int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphContext** out);
+int32_t sph_destroy(SphContext* ctx);
+const char* sph_last_error(const SphContext* ctx);
+int32_t sph_set_option(SphContext* ctx, int32_t option, int32_t value);
+int32_t sph_get_option(const SphContext* ctx, int32_t option, int32_t* value);
+/* Replace the solver scalars (WCSPHSolver.__init__, WCSPH.py:6-16); the sizes in
+ * `params` (n_particles, capacity, grid_num, cell_origin, n_objects) must be unchanged. */
+int32_t sph_set_params(SphContext* ctx, const SphParams* params);
+int32_t sph_set_dt(SphContext* ctx, float dt);                        /* solver.dt[None] = ..  sph_base.py:20-21 */
+int32_t sph_set_particle_count(SphContext* ctx, int32_t n);           /* owned+ghost count (multi-GPU) */
+
+/* ti.field.from_numpy / to_numpy / _add_particles (particle_system.py:260-284,
+ * 409-418).  `host` is borrowed for the duration of the call. */
+int32_t sph_upload(SphContext* ctx, int32_t field, const void* host, size_t bytes);
+int32_t sph_download(SphContext* ctx, int32_t field, void* host, size_t bytes);
+
+/* --- K1-K3: neighbour structure (particle_system.py:311-375) --- */
+int32_t sph_update_grid_id(SphContext* ctx);       /* update_grid_id          :311-320 */
+int32_t sph_prefix_sum(SphContext* ctx);           /* PrefixSumExecutor.run   :374 (scan_single_buffer.py:108-146) */
+int32_t sph_counting_sort(SphContext* ctx);        /* counting_sort           :322-369 */
+int32_t sph_initialize_particle_system(SphContext* ctx); /* :372-375 */
+
+/* --- K4-K10: solver kernels --- */
+int32_t sph_compute_boundary_volume(SphContext* ctx, int32_t dynamic); /* sph_base.py:91-98 (0) / :106-113 (1) */
+int32_t sph_compute_densities(SphContext* ctx);             /* WCSPH.py:33-43 */
+int32_t sph_compute_non_pressure_forces(SphContext* ctx);   /* WCSPH.py:128-140 */
+int32_t sph_compute_pressure_forces(SphContext* ctx);       /* WCSPH.py:70-85 */
+int32_t sph_advect(SphContext* ctx);                        /* WCSPH.py:143-149 */
+int32_t sph_enforce_boundary_3D(SphContext* ctx, int32_t particle_type); /* sph_base.py:149-179 */
+int32_t sph_compute_rigid_rest_cm(SphContext* ctx, int32_t object_id);   /* sph_base.py:87-89 */
+/* solve_constraints (sph_base.py:200-222).  R_out (9 floats, row-major) may be
+ * NULL; when non-NULL the call synchronises, like the reference's return. */
+int32_t sph_solve_constraints(SphContext* ctx, int32_t object_id, float* R_out);
+/* compute_com_kernel (sph_base.py:195-197); synchronises. */
+int32_t sph_compute_com(SphContext* ctx, int32_t object_id, float* cm_out);
+
+/* SPHBase.step() x n_steps (sph_base.py:263-271) entirely on the device.
+ * dynamic_ids = objectIds of dynamic RigidBodies (sph_base.py:249-250). */
+int32_t sph_step(SphContext* ctx, int32_t n_steps, const int32_t* dynamic_ids, int32_t n_dynamic);
+
+int32_t sph_sync(SphContext* ctx);
+int32_t sph_get_timings(SphContext* ctx, SphTimings* out);
+int32_t sph_reset_timings(SphContext* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPH_HIP_H */

@@ -1,0 +1,117 @@
+"""ctypes binding of libsph_hip.so (C ABI: include/sph_hip.h).
+
+The product path has no fallback: if the shared library is missing (and cannot
+be built) or no gfx950 device is visible, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+_F3 = C.c_float * 3
+_I3 = C.c_int32 * 3
+
+
+class SphParams(C.Structure):
+    """Mirror of `struct SphParams` (include/sph_hip.h)."""
+    _fields_ = [
+        ("n_particles", C.c_int32), ("capacity", C.c_int32), ("grid_num", _I3), ("cell_origin", _I3),
+        ("n_objects", C.c_int32),
+        ("grid_size", C.c_float), ("support_radius", C.c_float), ("particle_diameter", C.c_float),
+        ("m_V0", C.c_float), ("density_0", C.c_float), ("stiffness", C.c_float), ("exponent", C.c_float),
+        ("viscosity", C.c_float), ("surface_tension", C.c_float), ("dt", C.c_float),
+        ("g", _F3), ("domain_size", _F3), ("padding", C.c_float), ("wall_hi", _F3),
+        ("k_w", C.c_float), ("k_dw", C.c_float), ("visc_d_nu", C.c_float), ("visc_eps", C.c_float),
+    ]
+
+
+class SphTimings(C.Structure):
+    _fields_ = [("sort_ms", C.c_double), ("neighbour_ms", C.c_double), ("force_ms", C.c_double),
+                ("integrate_ms", C.c_double), ("halo_ms", C.c_double), ("total_ms", C.c_double),
+                ("steps", C.c_int64)]
+
+
+# enum SphField
+F_OBJECT_ID, F_X, F_X_0, F_V, F_ACCELERATION, F_M_V, F_M, F_DENSITY, F_PRESSURE, F_MATERIAL, F_COLOR, \
+    F_IS_DYNAMIC, F_GRID_IDS, F_GRID_PARTICLES_NUM, F_PID, F_RIGID_REST_CM = range(16)
+# enum SphOption
+OPT_GATHER_IMPL, OPT_TIMING, OPT_FUSED_STEP, OPT_BRICK_SHAPE = range(4)
+
+ABI_VERSION = 1
+
+# every symbol include/sph_hip.h declares: (name, restype, argtypes)
+_ctx = C.c_void_p
+SYMBOLS = [
+    ("sph_abi_version", C.c_int32, []),
+    ("sph_device_count", C.c_int32, []),
+    ("sph_create", C.c_int32, [C.POINTER(SphParams), C.c_int32, C.c_void_p, C.POINTER(_ctx)]),
+    ("sph_destroy", C.c_int32, [_ctx]),
+    ("sph_last_error", C.c_char_p, [_ctx]),
+    ("sph_set_option", C.c_int32, [_ctx, C.c_int32, C.c_int32]),
+    ("sph_get_option", C.c_int32, [_ctx, C.c_int32, C.POINTER(C.c_int32)]),
+    ("sph_set_params", C.c_int32, [_ctx, C.POINTER(SphParams)]),
+    ("sph_set_dt", C.c_int32, [_ctx, C.c_float]),
+    ("sph_set_particle_count", C.c_int32, [_ctx, C.c_int32]),
+    ("sph_upload", C.c_int32, [_ctx, C.c_int32, C.c_void_p, C.c_size_t]),
+    ("sph_download", C.c_int32, [_ctx, C.c_int32, C.c_void_p, C.c_size_t]),
+    ("sph_update_grid_id", C.c_int32, [_ctx]),
+    ("sph_prefix_sum", C.c_int32, [_ctx]),
+    ("sph_counting_sort", C.c_int32, [_ctx]),
+    ("sph_initialize_particle_system", C.c_int32, [_ctx]),
+    ("sph_compute_boundary_volume", C.c_int32, [_ctx, C.c_int32]),
+    ("sph_compute_densities", C.c_int32, [_ctx]),
+    ("sph_compute_non_pressure_forces", C.c_int32, [_ctx]),
+    ("sph_compute_pressure_forces", C.c_int32, [_ctx]),
+    ("sph_advect", C.c_int32, [_ctx]),
+    ("sph_enforce_boundary_3D", C.c_int32, [_ctx, C.c_int32]),
+    ("sph_compute_rigid_rest_cm", C.c_int32, [_ctx, C.c_int32]),
+    ("sph_solve_constraints", C.c_int32, [_ctx, C.c_int32, C.POINTER(C.c_float)]),
+    ("sph_compute_com", C.c_int32, [_ctx, C.c_int32, C.POINTER(C.c_float)]),
+    ("sph_step", C.c_int32, [_ctx, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
+    ("sph_sync", C.c_int32, [_ctx]),
+    ("sph_get_timings", C.c_int32, [_ctx, C.POINTER(SphTimings)]),
+    ("sph_reset_timings", C.c_int32, [_ctx]),
+]
+
+_LIB = None
+
+
+class SphError(RuntimeError):
+    pass
+
+
+def library_path() -> str:
+    return _build.LIB
+
+
+def load(build_if_missing: bool = True):
+    """dlopen libsph_hip.so, binding every symbol of the header.  Raises if absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if build_if_missing and _build.stale():
+        try:
+            _build.build()
+        except Exception as e:  # no hipcc on this box: use the prebuilt file if any
+            if not os.path.exists(path):
+                raise SphError(f"libsph_hip.so is missing and could not be built: {e}") from e
+    if not os.path.exists(path):
+        raise SphError(f"{path} not found: run `python -m sph_taichi_amd.build` (needs hipcc)")
+    lib = C.CDLL(path)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sph_abi_version() != ABI_VERSION:
+        raise SphError(f"libsph_hip ABI {lib.sph_abi_version()} != binding {ABI_VERSION}")
+    _LIB = lib
+    return lib
+
+
+def check(lib, ctx, rc: int, what: str):
+    if rc != 0:
+        msg = lib.sph_last_error(ctx)
+        raise SphError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")

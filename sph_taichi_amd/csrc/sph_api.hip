@@ -1,0 +1,489 @@
+// sph_api.hip -- the extern "C" surface declared in include/sph_hip.h: context
+// lifetime, field upload/download, one entry point per reference kernel, and
+// sph_step = SPHBase.step() (sph_base.py:263-271) looped on the device.
+#include "sph_internal.h"
+
+#define SCAN_TILE 2048
+
+int sphk_init_pid(SphContext* c);
+int sphk_build_dyn_list(SphContext* c);
+
+static thread_local char g_err[256] = "";
+
+int sph_fail(SphContext* c, int code, const char* what) {
+    if (c) snprintf(c->err, sizeof(c->err), "%s", what);
+    else snprintf(g_err, sizeof(g_err), "%s", what);
+    return code;
+}
+
+DevView sph_view(const SphContext* c) {
+    DevView d;
+    const SphParams& p = c->p;
+    d.N = c->N; d.G = c->G;
+    d.nx = p.grid_num[0]; d.ny = p.grid_num[1]; d.nz = p.grid_num[2];
+    d.ox = p.cell_origin[0]; d.oy = p.cell_origin[1]; d.oz = p.cell_origin[2];
+    d.grid_size = p.grid_size; d.h = p.support_radius; d.d = p.particle_diameter;
+    d.d2 = p.particle_diameter * p.particle_diameter;  // WCSPH.py:96
+    d.m_V0 = p.m_V0; d.rho0 = p.density_0; d.stiffness = p.stiffness; d.exponent = p.exponent;
+    d.sigma = p.surface_tension; d.dt = p.dt;
+    d.gx = p.g[0]; d.gy = p.g[1]; d.gz = p.g[2];
+    d.domx = p.domain_size[0]; d.domy = p.domain_size[1]; d.domz = p.domain_size[2]; d.pad = p.padding;
+    d.k_w = p.k_w; d.k_dw = p.k_dw; d.visc_d_nu = p.visc_d_nu; d.visc_eps = p.visc_eps;
+    d.w_zero = p.k_w * (6.0f * 0.0f - 6.0f * 0.0f + 1.0f);  // W(0), sph_base.py:41
+    {   // W(d): q = d/h (sph_base.py:36-44)
+        const float q = p.particle_diameter / p.support_radius;
+        if (q <= 0.5f) d.w_d = p.k_w * (6.0f * q * q * q - 6.0f * q * q + 1.0f);
+        else if (q <= 1.0f) d.w_d = p.k_w * 2.0f * (1.0f - q) * (1.0f - q) * (1.0f - q);
+        else d.w_d = 0.0f;
+    }
+    d.xm = c->xm[c->cur]; d.vf = c->vf[c->cur]; d.aux = c->aux[c->cur]; d.key = c->key[c->cur];
+    d.eos = c->eos; d.acc = c->acc; d.cell_end = c->cell_end;
+    d.x0_cold = c->x0_cold; d.rigid_rest_cm = c->rigid_rest_cm;
+    return d;
+}
+
+extern "C" {
+
+int32_t sph_abi_version(void) { return SPH_ABI_VERSION; }
+
+int32_t sph_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* sph_last_error(const SphContext* ctx) { return ctx ? ctx->err : g_err; }
+
+static int alloc_dev(SphContext* c, void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+    if (e != hipSuccess) {
+        snprintf(c->err, sizeof(c->err), "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return SPH_E_NOMEM;
+    }
+    e = hipMemsetAsync(*p, 0, bytes ? bytes : 16, c->stream);
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphContext** out) {
+    if (!params || !out) return sph_fail(nullptr, SPH_E_INVALID, "sph_create: null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return sph_fail(nullptr, SPH_E_NO_DEVICE, "sph_create: no HIP device visible (libsph_hip needs an MI355X/gfx950 GPU)");
+    if (device < 0 || device >= ndev) return sph_fail(nullptr, SPH_E_INVALID, "sph_create: bad device index");
+    if (params->n_particles < 0 || params->capacity < params->n_particles || params->grid_num[0] <= 0 ||
+        params->grid_num[1] <= 0 || params->grid_num[2] <= 0 || params->n_objects < 0)
+        return sph_fail(nullptr, SPH_E_INVALID, "sph_create: bad sizes");
+    if ((long long)params->grid_num[0] * params->grid_num[1] * params->grid_num[2] > 0x7ffff000LL)
+        return sph_fail(nullptr, SPH_E_INVALID, "sph_create: grid too large for i32 cell ids");
+    if (hipSetDevice(device) != hipSuccess) return sph_fail(nullptr, SPH_E_NO_DEVICE, "hipSetDevice failed");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        snprintf(g_err, sizeof(g_err), "sph_create: device arch %s is not gfx950", prop.gcnArchName);
+        return SPH_E_NO_DEVICE;
+    }
+    SphContext* c = new SphContext();
+    memset(c, 0, sizeof(*c));
+    c->p = *params;
+    c->device = device;
+    c->N = params->n_particles;
+    c->cap = params->capacity > 0 ? params->capacity : 1;
+    c->G = params->grid_num[0] * params->grid_num[1] * params->grid_num[2];
+    c->opt_gather_impl = 1;
+    c->opt_fused = 1;
+    c->opt_timing = 0;
+    c->opt_brick_shape = 0;
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete c;
+            return sph_fail(nullptr, SPH_E_NO_DEVICE, "hipStreamCreate failed");
+        }
+        c->own_stream = true;
+    }
+    const size_t cap = (size_t)c->cap;
+    c->scan_blocks = (c->G + SCAN_TILE - 1) / SCAN_TILE;
+    int rc = 0;
+    for (int s = 0; s < 2 && !rc; ++s) {
+        rc = rc ? rc : alloc_dev(c, (void**)&c->xm[s], cap * 16);
+        rc = rc ? rc : alloc_dev(c, (void**)&c->vf[s], cap * 16);
+        rc = rc ? rc : alloc_dev(c, (void**)&c->aux[s], cap * 16);
+        rc = rc ? rc : alloc_dev(c, (void**)&c->key[s], cap * 4);
+    }
+    rc = rc ? rc : alloc_dev(c, (void**)&c->eos, cap * 16);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->acc, cap * 16);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->acc_tmp, cap * 16);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->cell_end, (size_t)c->scan_blocks * SCAN_TILE * 4);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->rank_off, cap * 4);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->idx_unstable, cap * 4);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->scan_sums, (size_t)(c->scan_blocks + 1) * 4);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->x0_cold, cap * 12);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->color_cold, cap * 12);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->rigid_rest_cm, (size_t)(params->n_objects > 0 ? params->n_objects : 1) * 12);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->dyn_list, cap * 4);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->dyn_count, 16);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->rigid_accum, 16 * sizeof(double));
+    rc = rc ? rc : alloc_dev(c, (void**)&c->rigid_R, 16 * sizeof(float));
+    c->stage_bytes = cap * 16 > (size_t)c->G * 4 ? cap * 16 : (size_t)c->G * 4;
+    rc = rc ? rc : alloc_dev(c, &c->stage, c->stage_bytes);
+    if (!rc) rc = sphk_init_pid(c);
+    for (int s = 0; s < SPH_MAX_TIMED_STEPS && !rc; ++s)
+        for (int k = 0; k < 5 && !rc; ++k)
+            if (hipEventCreate(&c->ev[s][k]) != hipSuccess) rc = SPH_E_NOMEM;
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = SPH_E_NO_DEVICE;
+    if (rc) {
+        snprintf(g_err, sizeof(g_err), "sph_create failed: %s", c->err);
+        sph_destroy(c);
+        return rc;
+    }
+    c->n_dyn_host = -1;  // unknown until material / is_dynamic are uploaded
+    *out = c;
+    return 0;
+}
+
+int32_t sph_destroy(SphContext* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void* ptrs[] = {c->xm[0], c->xm[1], c->vf[0], c->vf[1], c->aux[0], c->aux[1], c->key[0], c->key[1], c->eos, c->acc,
+                    c->acc_tmp, c->cell_end, c->rank_off, c->idx_unstable, c->scan_sums, c->x0_cold, c->color_cold,
+                    c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->rigid_accum, c->rigid_R, c->stage};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (int s = 0; s < SPH_MAX_TIMED_STEPS; ++s)
+        for (int k = 0; k < 5; ++k) if (c->ev[s][k]) (void)hipEventDestroy(c->ev[s][k]);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int32_t sph_set_option(SphContext* c, int32_t option, int32_t value) {
+    if (!c) return SPH_E_INVALID;
+    switch (option) {
+        case SPH_OPT_GATHER_IMPL: if (value < 0 || value > 1) return sph_fail(c, SPH_E_INVALID, "gather impl must be 0 or 1"); c->opt_gather_impl = value; return 0;
+        case SPH_OPT_TIMING: c->opt_timing = value ? 1 : 0; return 0;
+        case SPH_OPT_FUSED_STEP: c->opt_fused = value ? 1 : 0; return 0;
+        case SPH_OPT_BRICK_SHAPE: if (value < 0 || value > 3) return sph_fail(c, SPH_E_INVALID, "brick shape must be 0..3"); c->opt_brick_shape = value; return 0;
+    }
+    return sph_fail(c, SPH_E_INVALID, "unknown option");
+}
+
+int32_t sph_get_option(const SphContext* c, int32_t option, int32_t* value) {
+    if (!c || !value) return SPH_E_INVALID;
+    switch (option) {
+        case SPH_OPT_GATHER_IMPL: *value = c->opt_gather_impl; return 0;
+        case SPH_OPT_TIMING: *value = c->opt_timing; return 0;
+        case SPH_OPT_FUSED_STEP: *value = c->opt_fused; return 0;
+        case SPH_OPT_BRICK_SHAPE: *value = c->opt_brick_shape; return 0;
+    }
+    return SPH_E_INVALID;
+}
+
+int32_t sph_set_params(SphContext* c, const SphParams* p) {
+    if (!c || !p) return SPH_E_INVALID;
+    if (p->capacity != c->p.capacity || p->n_objects != c->p.n_objects ||
+        memcmp(p->grid_num, c->p.grid_num, sizeof(p->grid_num)) != 0 ||
+        memcmp(p->cell_origin, c->p.cell_origin, sizeof(p->cell_origin)) != 0)
+        return sph_fail(c, SPH_E_INVALID, "sph_set_params: sizes differ from sph_create");
+    const int n = c->p.n_particles;
+    c->p = *p;
+    c->p.n_particles = n;
+    return 0;
+}
+
+int32_t sph_set_dt(SphContext* c, float dt) {
+    if (!c) return SPH_E_INVALID;
+    c->p.dt = dt;
+    return 0;
+}
+
+int32_t sph_set_particle_count(SphContext* c, int32_t n) {
+    if (!c || n < 0 || n > c->cap) return sph_fail(c, SPH_E_INVALID, "particle count out of range");
+    c->N = n;
+    c->n_dyn_host = -1;
+    c->have_keys = c->have_prefix = false;
+    return 0;
+}
+
+static size_t field_bytes(const SphContext* c, int field) {
+    switch (field) {
+        case SPH_F_X: case SPH_F_X_0: case SPH_F_V: case SPH_F_ACCELERATION: case SPH_F_COLOR: return (size_t)c->N * 12;
+        case SPH_F_GRID_PARTICLES_NUM: return (size_t)c->G * 4;
+        case SPH_F_RIGID_REST_CM: return (size_t)c->p.n_objects * 12;
+        default: return (size_t)c->N * 4;
+    }
+}
+
+int32_t sph_upload(SphContext* c, int32_t field, const void* host, size_t bytes) {
+    if (!c || !host) return SPH_E_INVALID;
+    if (field < 0 || field >= SPH_F_COUNT_ || field == SPH_F_GRID_IDS || field == SPH_F_GRID_PARTICLES_NUM ||
+        field == SPH_F_PID)
+        return sph_fail(c, SPH_E_INVALID, "sph_upload: field is not uploadable");
+    if (bytes != field_bytes(c, field)) return sph_fail(c, SPH_E_INVALID, "sph_upload: size mismatch");
+    SPH_HIP(c, hipSetDevice(c->device));
+    if (bytes == 0) return 0;
+    if (field == SPH_F_RIGID_REST_CM) {
+        SPH_HIP(c, hipMemcpyAsync(c->rigid_rest_cm, host, bytes, hipMemcpyHostToDevice, c->stream));
+        SPH_HIP(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
+    SPH_HIP(c, hipMemcpyAsync(c->stage, host, bytes, hipMemcpyHostToDevice, c->stream));
+    int rc = sphk_insert(c, field, c->stage);
+    if (rc) return rc;
+    SPH_HIP(c, hipStreamSynchronize(c->stream));  // host buffer is only borrowed for the call
+    if (field == SPH_F_MATERIAL || field == SPH_F_IS_DYNAMIC) c->n_dyn_host = -1;
+    if (field == SPH_F_X) c->have_keys = c->have_prefix = false;
+    return 0;
+}
+
+int32_t sph_download(SphContext* c, int32_t field, void* host, size_t bytes) {
+    if (!c || !host) return SPH_E_INVALID;
+    if (field < 0 || field >= SPH_F_COUNT_) return sph_fail(c, SPH_E_INVALID, "sph_download: bad field");
+    if (bytes != field_bytes(c, field)) return sph_fail(c, SPH_E_INVALID, "sph_download: size mismatch");
+    SPH_HIP(c, hipSetDevice(c->device));
+    if (bytes == 0) return 0;
+    const void* src = c->stage;
+    if (field == SPH_F_GRID_PARTICLES_NUM) src = c->cell_end;
+    else if (field == SPH_F_RIGID_REST_CM) src = c->rigid_rest_cm;
+    else {
+        int rc = sphk_extract(c, field, c->stage);
+        if (rc) return rc;
+    }
+    SPH_HIP(c, hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    SPH_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// number (and current-order list) of dynamic rigid particles; refreshed lazily
+static int refresh_dyn(SphContext* c) {
+    if (c->n_dyn_host >= 0) return 0;
+    int rc = sphk_build_dyn_list(c);
+    if (rc) return rc;
+    int n = 0;
+    SPH_HIP(c, hipMemcpyAsync(&n, c->dyn_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    SPH_HIP(c, hipStreamSynchronize(c->stream));
+    c->n_dyn_host = n;
+    return 0;
+}
+
+#define ENTER(c)                                  \
+    if (!(c)) return SPH_E_INVALID;               \
+    SPH_HIP((c), hipSetDevice((c)->device));
+
+int32_t sph_update_grid_id(SphContext* c) {
+    ENTER(c);
+    int rc = sphk_hash_histogram(c);
+    if (rc) return rc;
+    c->have_keys = true;
+    c->have_prefix = false;
+    return 0;
+}
+
+int32_t sph_prefix_sum(SphContext* c) {
+    ENTER(c);
+    if (!c->have_keys) return sph_fail(c, SPH_E_STATE, "sph_prefix_sum before sph_update_grid_id");
+    int rc = sphk_scan(c);
+    if (rc) return rc;
+    c->have_prefix = true;
+    return 0;
+}
+
+static int counting_sort(SphContext* c, bool sort_acc) {
+    if (!c->have_prefix) return sph_fail(c, SPH_E_STATE, "sph_counting_sort before sph_prefix_sum");
+    int rc = refresh_dyn(c);
+    if (rc) return rc;
+    rc = sphk_sort_scatter(c, sort_acc);
+    if (rc) return rc;
+    c->have_keys = false;  // the histogram offsets are consumed
+    c->sorted = true;
+    return 0;
+}
+
+int32_t sph_counting_sort(SphContext* c) {
+    ENTER(c);
+    return counting_sort(c, true);
+}
+
+int32_t sph_initialize_particle_system(SphContext* c) {
+    ENTER(c);
+    int rc = sph_update_grid_id(c);
+    rc = rc ? rc : sph_prefix_sum(c);
+    rc = rc ? rc : counting_sort(c, true);
+    return rc;
+}
+
+static int need_sorted(SphContext* c, const char* who) {
+    if (!c->sorted || !c->have_prefix) {
+        snprintf(c->err, sizeof(c->err), "%s needs the neighbour structure: call sph_initialize_particle_system first", who);
+        return SPH_E_STATE;
+    }
+    return 0;
+}
+
+int32_t sph_compute_boundary_volume(SphContext* c, int32_t dynamic) {
+    ENTER(c);
+    int rc = need_sorted(c, "sph_compute_boundary_volume");
+    rc = rc ? rc : refresh_dyn(c);
+    return rc ? rc : sphk_gather(c, dynamic ? GM_BVOL_DYNAMIC : GM_BVOL_STATIC);
+}
+
+int32_t sph_compute_densities(SphContext* c) {
+    ENTER(c);
+    int rc = need_sorted(c, "sph_compute_densities");
+    return rc ? rc : sphk_gather(c, GM_DENSITY);
+}
+
+int32_t sph_compute_non_pressure_forces(SphContext* c) {
+    ENTER(c);
+    int rc = need_sorted(c, "sph_compute_non_pressure_forces");
+    return rc ? rc : sphk_gather(c, GM_NONPRESSURE);
+}
+
+int32_t sph_compute_pressure_forces(SphContext* c) {
+    ENTER(c);
+    int rc = need_sorted(c, "sph_compute_pressure_forces");
+    rc = rc ? rc : sphk_eos(c);                      // WCSPH.py:71-76
+    return rc ? rc : sphk_gather(c, GM_PRESSURE);    // WCSPH.py:77-85
+}
+
+int32_t sph_advect(SphContext* c) {
+    ENTER(c);
+    return sphk_advect(c, false);
+}
+
+int32_t sph_enforce_boundary_3D(SphContext* c, int32_t particle_type) {
+    ENTER(c);
+    int rc = refresh_dyn(c);
+    return rc ? rc : sphk_enforce_boundary(c, particle_type);
+}
+
+int32_t sph_compute_rigid_rest_cm(SphContext* c, int32_t object_id) {
+    ENTER(c);
+    if (object_id < 0 || object_id >= c->p.n_objects) return sph_fail(c, SPH_E_INVALID, "object id out of range");
+    int rc = refresh_dyn(c);
+    return rc ? rc : sphk_rigid_com(c, object_id, true);
+}
+
+int32_t sph_solve_constraints(SphContext* c, int32_t object_id, float* R_out) {
+    ENTER(c);
+    if (object_id < 0 || object_id >= c->p.n_objects) return sph_fail(c, SPH_E_INVALID, "object id out of range");
+    int rc = refresh_dyn(c);
+    rc = rc ? rc : sphk_rigid_solve(c, object_id);
+    if (rc) return rc;
+    if (R_out) {
+        float tmp[12] = {0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (c->n_dyn_host > 0) {
+            SPH_HIP(c, hipMemcpyAsync(tmp, c->rigid_R, sizeof(tmp), hipMemcpyDeviceToHost, c->stream));
+            SPH_HIP(c, hipStreamSynchronize(c->stream));
+        }
+        memcpy(R_out, tmp + 3, 9 * sizeof(float));
+    }
+    return 0;
+}
+
+int32_t sph_compute_com(SphContext* c, int32_t object_id, float* cm_out) {
+    ENTER(c);
+    if (!cm_out) return SPH_E_INVALID;
+    int rc = refresh_dyn(c);
+    rc = rc ? rc : sphk_rigid_com(c, object_id, false);
+    if (rc) return rc;
+    double acc[4];
+    SPH_HIP(c, hipMemcpyAsync(acc, c->rigid_accum, sizeof(acc), hipMemcpyDeviceToHost, c->stream));
+    SPH_HIP(c, hipStreamSynchronize(c->stream));
+    const float sum_m = (float)acc[0];
+    for (int k = 0; k < 3; ++k) cm_out[k] = (float)acc[1 + k] / sum_m;
+    return 0;
+}
+
+static int harvest_events(SphContext* c) {
+    if (c->ev_used == 0) return 0;
+    SPH_HIP(c, hipEventSynchronize(c->ev[c->ev_used - 1][4]));
+    for (int s = 0; s < c->ev_used; ++s) {
+        float ms[4];
+        for (int k = 0; k < 4; ++k) SPH_HIP(c, hipEventElapsedTime(&ms[k], c->ev[s][k], c->ev[s][k + 1]));
+        c->tm.sort_ms += ms[0];
+        c->tm.neighbour_ms += ms[1];
+        c->tm.force_ms += ms[2];
+        c->tm.integrate_ms += ms[3];
+        c->tm.total_ms += ms[0] + ms[1] + ms[2] + ms[3];
+        c->tm.steps += 1;
+    }
+    c->ev_used = 0;
+    return 0;
+}
+
+int32_t sph_step(SphContext* c, int32_t n_steps, const int32_t* dynamic_ids, int32_t n_dynamic) {
+    ENTER(c);
+    if (n_steps < 0 || n_dynamic < 0 || (n_dynamic > 0 && !dynamic_ids)) return sph_fail(c, SPH_E_INVALID, "sph_step: bad arguments");
+    int rc = refresh_dyn(c);
+    if (rc) return rc;
+    const bool timing = c->opt_timing != 0;
+    for (int it = 0; it < n_steps; ++it) {
+        hipEvent_t* ev = nullptr;
+        if (timing) {
+            if (c->ev_used == SPH_MAX_TIMED_STEPS) { rc = harvest_events(c); if (rc) return rc; }
+            ev = c->ev[c->ev_used];
+            SPH_HIP(c, hipEventRecord(ev[0], c->stream));
+        }
+        // ps.initialize_particle_system()                      sph_base.py:264
+        rc = sph_update_grid_id(c);
+        rc = rc ? rc : sph_prefix_sum(c);
+        rc = rc ? rc : counting_sort(c, false);  // acceleration is dead here: every particle's a is rewritten below
+        if (rc) return rc;
+        if (timing) SPH_HIP(c, hipEventRecord(ev[1], c->stream));
+        // compute_moving_boundary_volume()                     sph_base.py:265
+        if (c->n_dyn_host > 0) { rc = sphk_gather(c, GM_BVOL_DYNAMIC); if (rc) return rc; }
+        if (c->opt_fused) {
+            rc = sphk_gather(c, GM_DENSITY_EOS);                // WCSPH.py:153 (+ EOS of :74-76)
+            if (rc) return rc;
+            if (timing) SPH_HIP(c, hipEventRecord(ev[2], c->stream));
+            rc = sphk_gather(c, GM_FORCE_FUSED);                // WCSPH.py:154-155
+            if (rc) return rc;
+        } else {
+            rc = sphk_gather(c, GM_DENSITY);
+            if (rc) return rc;
+            if (timing) SPH_HIP(c, hipEventRecord(ev[2], c->stream));
+            rc = sphk_gather(c, GM_NONPRESSURE);
+            rc = rc ? rc : sphk_eos(c);
+            rc = rc ? rc : sphk_gather(c, GM_PRESSURE);
+            if (rc) return rc;
+        }
+        if (timing) SPH_HIP(c, hipEventRecord(ev[3], c->stream));
+        // advect (WCSPH.py:156) + enforce_boundary_3D(fluid) (sph_base.py:270-271) in one pass
+        rc = sphk_advect(c, true);
+        if (rc) return rc;
+        // solve_rigid_body()                                   sph_base.py:247-260
+        if (c->n_dyn_host > 0)
+            for (int k = 0; k < n_dynamic; ++k) {
+                rc = sphk_rigid_solve(c, dynamic_ids[k]);
+                rc = rc ? rc : sphk_enforce_boundary(c, SPH_MATERIAL_SOLID);
+                if (rc) return rc;
+            }
+        if (timing) { SPH_HIP(c, hipEventRecord(ev[4], c->stream)); c->ev_used++; }
+    }
+    return 0;
+}
+
+int32_t sph_sync(SphContext* c) {
+    ENTER(c);
+    SPH_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int32_t sph_get_timings(SphContext* c, SphTimings* out) {
+    ENTER(c);
+    if (!out) return SPH_E_INVALID;
+    int rc = harvest_events(c);
+    if (rc) return rc;
+    *out = c->tm;
+    return 0;
+}
+
+int32_t sph_reset_timings(SphContext* c) {
+    ENTER(c);
+    int rc = harvest_events(c);
+    if (rc) return rc;
+    memset(&c->tm, 0, sizeof(c->tm));
+    return 0;
+}
+
+}  // extern "C"

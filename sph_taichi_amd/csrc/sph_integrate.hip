@@ -1,0 +1,438 @@
+// sph_integrate.hip -- K8..K11 of the hot path: symplectic Euler (WCSPH.py:
+// 143-149), domain walls (sph_base.py:118-123, 149-179), shape-matching rigid
+// bodies (sph_base.py:87-89, 182-222), plus the field insert/extract kernels
+// behind sph_upload / sph_download.  All streaming, HBM-bound.
+#include "sph_internal.h"
+
+#define TPB 256
+
+// sph_base.py:149-179 enforce_boundary_3D body for one particle
+__device__ __forceinline__ void wall_collide(const DevView& d, const float hi[3], float4& xm, float4& vf) {
+    const float pos[3] = {xm.x, xm.y, xm.z};
+    float x[3] = {xm.x, xm.y, xm.z};
+    float n[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (pos[a] > hi[a]) { n[a] += 1.0f; x[a] = hi[a]; }
+        if (pos[a] <= d.pad) { n[a] += -1.0f; x[a] = d.pad; }
+    }
+    xm.x = x[0]; xm.y = x[1]; xm.z = x[2];
+    const float len = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    if (len > 1e-6f) {
+        // sph_base.py:118-123 simulate_collisions, c_f = 0.5
+        const float vx_ = n[0] / len, vy_ = n[1] / len, vz_ = n[2] / len;
+        const float vd = vf.x * vx_ + vf.y * vy_ + vf.z * vz_;
+        vf.x -= (1.0f + 0.5f) * vd * vx_;
+        vf.y -= (1.0f + 0.5f) * vd * vy_;
+        vf.z -= (1.0f + 0.5f) * vd * vz_;
+    }
+}
+
+struct WallHi { float v[3]; };
+
+// WCSPH.py:143-149 advect; FLUID_WALLS additionally applies
+// enforce_boundary_3D(material_fluid) (sph_base.py:270-271) to fluid particles in
+// the same pass (it only touches fluid, so it commutes with the rigid solve).
+template <bool FLUID_WALLS>
+__global__ __launch_bounds__(TPB) void k_advect(DevView d, WallHi hi) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= d.N) return;
+    float4 vf = d.vf[i];
+    const int fl = __float_as_int(vf.w);
+    if (!sph_flags_dynamic(fl)) return;
+    float4 xm = d.xm[i];
+    const float4 a = d.acc[i];
+    vf.x += d.dt * a.x; vf.y += d.dt * a.y; vf.z += d.dt * a.z;
+    xm.x += d.dt * vf.x; xm.y += d.dt * vf.y; xm.z += d.dt * vf.z;
+    if (FLUID_WALLS && sph_is_fluid(fl)) wall_collide(d, hi.v, xm, vf);
+    d.xm[i] = xm;
+    d.vf[i] = vf;
+}
+
+__global__ __launch_bounds__(TPB) void k_enforce_boundary(DevView d, WallHi hi, int particle_type,
+                                                          const int* __restrict__ list, int n) {
+    const int tix = blockIdx.x * TPB + threadIdx.x;
+    if (tix >= n) return;
+    const int i = list ? list[tix] : tix;
+    float4 vf = d.vf[i];
+    const int fl = __float_as_int(vf.w);
+    if (!(sph_flags_material(fl) == particle_type && sph_flags_dynamic(fl))) return;
+    float4 xm = d.xm[i];
+    wall_collide(d, hi.v, xm, vf);
+    d.xm[i] = xm;
+    d.vf[i] = vf;
+}
+
+// ---- rigid bodies -----------------------------------------------------------
+// accum[0] = sum m, accum[1..3] = sum m x, accum[4..12] = A (row-major)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// sph_base.py:182-192 compute_com (mass = m_V0 * density)
+__global__ __launch_bounds__(TPB) void k_rigid_sum(DevView d, const int* __restrict__ list, int n, int object_id,
+                                                   double* __restrict__ accum) {
+    const int tix = blockIdx.x * TPB + threadIdx.x;
+    double s[4] = {0, 0, 0, 0};
+    if (tix < n) {
+        const int i = list[tix];
+        const int fl = __float_as_int(d.vf[i].w);
+        if (sph_is_dynamic_rigid(fl) && sph_flags_object(fl) == object_id) {
+            const float4 xm = d.xm[i];
+            const float mass = d.m_V0 * d.aux[i].y;
+            s[0] = mass; s[1] = (double)(mass * xm.x); s[2] = (double)(mass * xm.y); s[3] = (double)(mass * xm.z);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double w = wave_sum(s[k]);
+        if ((threadIdx.x & 63) == 0 && w != 0.0) unsafeAtomicAdd(&accum[k], w);
+    }
+}
+
+// sph_base.py:206-210: A = sum m (x - cm) (x_0 - cm_rest)^T
+__global__ __launch_bounds__(TPB) void k_rigid_A(DevView d, const int* __restrict__ list, int n, int object_id,
+                                                 double* __restrict__ accum) {
+    const int tix = blockIdx.x * TPB + threadIdx.x;
+    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (tix < n) {
+        const int i = list[tix];
+        const int fl = __float_as_int(d.vf[i].w);
+        if (sph_is_dynamic_rigid(fl) && sph_flags_object(fl) == object_id) {
+            const float sum_m = (float)accum[0];  // same f32 division as k_rigid_finalize
+            const float cm[3] = {(float)accum[1] / sum_m, (float)accum[2] / sum_m, (float)accum[3] / sum_m};
+            const float4 xm = d.xm[i];
+            const float4 aux = d.aux[i];
+            const int pid = __float_as_int(aux.w);
+            const float* rc = &d.rigid_rest_cm[3 * object_id];
+            const float q[3] = {d.x0_cold[3 * pid] - rc[0], d.x0_cold[3 * pid + 1] - rc[1],
+                                d.x0_cold[3 * pid + 2] - rc[2]};
+            const float p[3] = {xm.x - cm[0], xm.y - cm[1], xm.z - cm[2]};
+            const float w = d.m_V0 * aux.y;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) s[3 * a + b] = (double)(w * (p[a] * q[b]));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const double w = wave_sum(s[k]);
+        if ((threadIdx.x & 63) == 0 && w != 0.0) unsafeAtomicAdd(&accum[4 + k], w);
+    }
+}
+
+// Rotation factor of A = R S (ti.polar_decompose, sph_base.py:212: third-party
+// Taichi SVD, det U = det V = +1 => closest proper rotation).  f64 Jacobi on
+// A^T A; one lane.
+__device__ void polar_rotation(const double A[3][3], float R_[9]) {
+    double S[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            S[i][j] = 0;
+            for (int k = 0; k < 3; ++k) S[i][j] += A[k][i] * A[k][j];
+        }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        const double off = fabs(S[0][1]) + fabs(S[0][2]) + fabs(S[1][2]);
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (fabs(S[p][q]) < 1e-300) continue;
+                const double theta = (S[q][q] - S[p][p]) / (2.0 * S[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 3; ++k) {
+                    const double skp = S[k][p], skq = S[k][q];
+                    S[k][p] = c * skp - sn * skq; S[k][q] = sn * skp + c * skq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double spk = S[p][k], sqk = S[q][k];
+                    S[p][k] = c * spk - sn * sqk; S[q][k] = sn * spk + c * sqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    int idx[3] = {0, 1, 2};
+    for (int i = 0; i < 2; ++i)
+        for (int j = i + 1; j < 3; ++j)
+            if (S[idx[j]][idx[j]] > S[idx[i]][idx[i]]) { const int t = idx[i]; idx[i] = idx[j]; idx[j] = t; }
+    double Vs[3][3], U[3][3], sig0;
+    for (int c = 0; c < 3; ++c)
+        for (int r = 0; r < 3; ++r) Vs[r][c] = V[r][idx[c]];
+    { const double e = S[idx[0]][idx[0]]; sig0 = e > 0 ? sqrt(e) : 0.0; }
+    const double detV = Vs[0][0] * (Vs[1][1] * Vs[2][2] - Vs[1][2] * Vs[2][1]) -
+                        Vs[0][1] * (Vs[1][0] * Vs[2][2] - Vs[1][2] * Vs[2][0]) +
+                        Vs[0][2] * (Vs[1][0] * Vs[2][1] - Vs[1][1] * Vs[2][0]);
+    if (detV < 0) for (int r = 0; r < 3; ++r) Vs[r][2] = -Vs[r][2];
+    if (sig0 <= 1e-300) {
+        for (int i = 0; i < 9; ++i) R_[i] = 0.0f;
+        return;
+    }
+    for (int c = 0; c < 2; ++c) {
+        double u[3];
+        for (int r = 0; r < 3; ++r) {
+            u[r] = 0;
+            for (int k = 0; k < 3; ++k) u[r] += A[r][k] * Vs[k][c];
+        }
+        double n = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        if (c == 1) {
+            const double dd = u[0] * U[0][0] + u[1] * U[1][0] + u[2] * U[2][0];
+            for (int r = 0; r < 3; ++r) u[r] -= dd * U[r][0];
+            n = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        }
+        if (n < 1e-300) {
+            double a[3] = {1, 0, 0};
+            if (c == 1) {
+                if (fabs(U[0][0]) > 0.9) { a[0] = 0; a[1] = 1; }
+                const double dd = a[0] * U[0][0] + a[1] * U[1][0] + a[2] * U[2][0];
+                for (int r = 0; r < 3; ++r) u[r] = a[r] - dd * U[r][0];
+            } else {
+                for (int r = 0; r < 3; ++r) u[r] = a[r];
+            }
+            n = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+        }
+        for (int r = 0; r < 3; ++r) U[r][c] = u[r] / n;
+    }
+    U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+    U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+    U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double r = 0;
+            for (int k = 0; k < 3; ++k) r += U[i][k] * Vs[j][k];
+            R_[3 * i + j] = (float)r;
+        }
+}
+
+// out[0..2] = cm, out[3..11] = R.  mode 0: cm only -> rigid_rest_cm[object_id]
+// (sph_base.py:87-89, NaN = 0/0 for static bodies like the reference);
+// mode 1: cm + polar(A) (sph_base.py:212-215).
+__global__ void k_rigid_finalize(DevView d, const double* __restrict__ accum, int object_id, int mode,
+                                 float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // f32 division like the reference's cm /= sum_m
+    const float sum_m = (float)accum[0];
+    const float cm[3] = {(float)accum[1] / sum_m, (float)accum[2] / sum_m, (float)accum[3] / sum_m};
+    out[0] = cm[0]; out[1] = cm[1]; out[2] = cm[2];
+    if (mode == 0) {
+        d.rigid_rest_cm[3 * object_id + 0] = cm[0];
+        d.rigid_rest_cm[3 * object_id + 1] = cm[1];
+        d.rigid_rest_cm[3 * object_id + 2] = cm[2];
+        return;
+    }
+    double A[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) A[i][j] = (double)(float)accum[4 + 3 * i + j];
+    float R[9];
+    polar_rotation(A, R);
+    bool all_small = true;
+    for (int i = 0; i < 9; ++i)
+        if (!(fabsf(R[i]) < 1e-6f)) all_small = false;
+    if (all_small) {  // sph_base.py:214-215
+        for (int i = 0; i < 9; ++i) R[i] = 0.0f;
+        R[0] = R[4] = R[8] = 1.0f;
+    }
+    for (int i = 0; i < 9; ++i) out[3 + i] = R[i];
+}
+
+// sph_base.py:217-221: x = cm + R (x_0 - cm_rest)
+__global__ __launch_bounds__(TPB) void k_rigid_apply(DevView d, const int* __restrict__ list, int n, int object_id,
+                                                     const float* __restrict__ cmR) {
+    const int tix = blockIdx.x * TPB + threadIdx.x;
+    if (tix >= n) return;
+    const int i = list[tix];
+    const int fl = __float_as_int(d.vf[i].w);
+    if (!(sph_is_dynamic_rigid(fl) && sph_flags_object(fl) == object_id)) return;
+    const int pid = __float_as_int(d.aux[i].w);
+    const float* rc = &d.rigid_rest_cm[3 * object_id];
+    const float q[3] = {d.x0_cold[3 * pid] - rc[0], d.x0_cold[3 * pid + 1] - rc[1], d.x0_cold[3 * pid + 2] - rc[2]};
+    float4 xm = d.xm[i];
+    float x[3] = {xm.x, xm.y, xm.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float goal = cmR[a] + (cmR[3 + 3 * a] * q[0] + cmR[3 + 3 * a + 1] * q[1] + cmR[3 + 3 * a + 2] * q[2]);
+        const float corr = (goal - x[a]) * 1.0f;
+        x[a] += corr;
+    }
+    xm.x = x[0]; xm.y = x[1]; xm.z = x[2];
+    d.xm[i] = xm;
+}
+
+// list of dynamic rigid particles in the CURRENT order (used before the first sort)
+__global__ __launch_bounds__(TPB) void k_build_dyn_list(DevView d, int* __restrict__ list, int* __restrict__ count) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= d.N) return;
+    if (sph_is_dynamic_rigid(__float_as_int(d.vf[i].w))) list[atomicAdd(count, 1)] = i;
+}
+
+// ---- field insert / extract (sph_upload / sph_download) -------------------
+__global__ __launch_bounds__(TPB) void k_extract(DevView d, int field, const int* __restrict__ color_cold,
+                                                 void* __restrict__ out) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= d.N) return;
+    float* of = reinterpret_cast<float*>(out);
+    int* oi = reinterpret_cast<int*>(out);
+    const int fl = __float_as_int(d.vf[i].w);
+    const int pid = __float_as_int(d.aux[i].w);
+    switch (field) {
+        case SPH_F_OBJECT_ID: oi[i] = sph_flags_object(fl); break;
+        case SPH_F_X: { const float4 v = d.xm[i]; of[3 * i] = v.x; of[3 * i + 1] = v.y; of[3 * i + 2] = v.z; } break;
+        case SPH_F_X_0: for (int k = 0; k < 3; ++k) of[3 * i + k] = d.x0_cold[3 * pid + k]; break;
+        case SPH_F_V: { const float4 v = d.vf[i]; of[3 * i] = v.x; of[3 * i + 1] = v.y; of[3 * i + 2] = v.z; } break;
+        case SPH_F_ACCELERATION: { const float4 v = d.acc[i]; of[3 * i] = v.x; of[3 * i + 1] = v.y; of[3 * i + 2] = v.z; } break;
+        case SPH_F_M_V: of[i] = d.xm[i].w; break;
+        case SPH_F_M: of[i] = d.aux[i].x; break;
+        case SPH_F_DENSITY: of[i] = d.aux[i].y; break;
+        case SPH_F_PRESSURE: of[i] = d.aux[i].z; break;
+        case SPH_F_MATERIAL: oi[i] = sph_flags_material(fl); break;
+        case SPH_F_COLOR: for (int k = 0; k < 3; ++k) oi[3 * i + k] = color_cold[3 * pid + k]; break;
+        case SPH_F_IS_DYNAMIC: oi[i] = sph_flags_dynamic(fl); break;
+        case SPH_F_GRID_IDS: oi[i] = d.key[i]; break;
+        case SPH_F_PID: oi[i] = pid; break;
+        default: break;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_insert(DevView d, int field, float* __restrict__ x0_cold,
+                                                int* __restrict__ color_cold, const void* __restrict__ in) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= d.N) return;
+    const float* f = reinterpret_cast<const float*>(in);
+    const int* n = reinterpret_cast<const int*>(in);
+    float* xm = reinterpret_cast<float*>(&d.xm[i]);
+    float* vf = reinterpret_cast<float*>(&d.vf[i]);
+    float* aux = reinterpret_cast<float*>(&d.aux[i]);
+    float* acc = reinterpret_cast<float*>(&d.acc[i]);
+    const int pid = __float_as_int(aux[3]);
+    int fl = __float_as_int(vf[3]);
+    switch (field) {
+        case SPH_F_OBJECT_ID: fl = (fl & 0x1FF) | (n[i] << 9); vf[3] = __int_as_float(fl); break;
+        case SPH_F_X: xm[0] = f[3 * i]; xm[1] = f[3 * i + 1]; xm[2] = f[3 * i + 2]; break;
+        case SPH_F_X_0: for (int k = 0; k < 3; ++k) x0_cold[3 * pid + k] = f[3 * i + k]; break;
+        case SPH_F_V: vf[0] = f[3 * i]; vf[1] = f[3 * i + 1]; vf[2] = f[3 * i + 2]; break;
+        case SPH_F_ACCELERATION: acc[0] = f[3 * i]; acc[1] = f[3 * i + 1]; acc[2] = f[3 * i + 2]; acc[3] = 0.f; break;
+        case SPH_F_M_V: xm[3] = f[i]; break;
+        case SPH_F_M: aux[0] = f[i]; break;
+        case SPH_F_DENSITY: aux[1] = f[i]; break;
+        case SPH_F_PRESSURE: aux[2] = f[i]; break;
+        case SPH_F_MATERIAL: fl = (fl & ~0xFF) | (n[i] & 0xFF); vf[3] = __int_as_float(fl); break;
+        case SPH_F_COLOR: for (int k = 0; k < 3; ++k) color_cold[3 * pid + k] = n[3 * i + k]; break;
+        case SPH_F_IS_DYNAMIC: fl = (fl & ~0x100) | (n[i] ? 0x100 : 0); vf[3] = __int_as_float(fl); break;
+        default: break;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_init_pid(float4* aux0, float4* aux1, int cap) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= cap) return;
+    aux0[i] = make_float4(0.f, 0.f, 0.f, __int_as_float(i));
+    aux1[i] = make_float4(0.f, 0.f, 0.f, __int_as_float(i));
+}
+
+// ---------------------------------------------------------------------------
+static WallHi wall_hi(const SphContext* c) {
+    WallHi w;
+    for (int k = 0; k < 3; ++k) w.v[k] = c->p.wall_hi[k];
+    return w;
+}
+
+int sphk_advect(SphContext* c, bool fused_fluid_walls) {
+    if (c->N <= 0) return 0;
+    DevView d = sph_view(c);
+    const int nb = (c->N + TPB - 1) / TPB;
+    if (fused_fluid_walls) hipLaunchKernelGGL(k_advect<true>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c));
+    else hipLaunchKernelGGL(k_advect<false>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c));
+    SPH_LAUNCH_CHECK(c);
+    return 0;
+}
+
+int sphk_enforce_boundary(SphContext* c, int particle_type) {
+    if (c->N <= 0) return 0;
+    DevView d = sph_view(c);
+    if (particle_type == SPH_MATERIAL_SOLID) {
+        // only dynamic solids can be hit: run over the dynamic-rigid list
+        if (c->n_dyn_host <= 0) return 0;
+        hipLaunchKernelGGL(k_enforce_boundary, dim3((c->n_dyn_host + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d,
+                           wall_hi(c), particle_type, c->dyn_list, c->n_dyn_host);
+    } else {
+        hipLaunchKernelGGL(k_enforce_boundary, dim3((c->N + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, wall_hi(c),
+                           particle_type, (const int*)nullptr, c->N);
+    }
+    SPH_LAUNCH_CHECK(c);
+    return 0;
+}
+
+// cm of object -> rigid_R[0..2] (and rigid_rest_cm[object] when to_rest)
+int sphk_rigid_com(SphContext* c, int object_id, bool to_rest) {
+    DevView d = sph_view(c);
+    SPH_HIP(c, hipMemsetAsync(c->rigid_accum, 0, sizeof(double) * 16, c->stream));
+    if (c->n_dyn_host > 0) {
+        hipLaunchKernelGGL(k_rigid_sum, dim3((c->n_dyn_host + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, c->dyn_list,
+                           c->n_dyn_host, object_id, c->rigid_accum);
+        SPH_LAUNCH_CHECK(c);
+    }
+    if (to_rest) {
+        hipLaunchKernelGGL(k_rigid_finalize, dim3(1), dim3(64), 0, c->stream, d, c->rigid_accum, object_id, 0,
+                           c->rigid_R);
+        SPH_LAUNCH_CHECK(c);
+    }
+    return 0;
+}
+
+// solve_constraints (sph_base.py:200-222) without any host round trip
+int sphk_rigid_solve(SphContext* c, int object_id) {
+    if (c->n_dyn_host <= 0) return 0;
+    int rc = sphk_rigid_com(c, object_id, false);
+    if (rc) return rc;
+    DevView d = sph_view(c);
+    const int nb = (c->n_dyn_host + TPB - 1) / TPB;
+    hipLaunchKernelGGL(k_rigid_A, dim3(nb), dim3(TPB), 0, c->stream, d, c->dyn_list, c->n_dyn_host, object_id,
+                       c->rigid_accum);
+    SPH_LAUNCH_CHECK(c);
+    hipLaunchKernelGGL(k_rigid_finalize, dim3(1), dim3(64), 0, c->stream, d, c->rigid_accum, object_id, 1, c->rigid_R);
+    SPH_LAUNCH_CHECK(c);
+    hipLaunchKernelGGL(k_rigid_apply, dim3(nb), dim3(TPB), 0, c->stream, d, c->dyn_list, c->n_dyn_host, object_id,
+                       c->rigid_R);
+    SPH_LAUNCH_CHECK(c);
+    return 0;
+}
+
+int sphk_extract(SphContext* c, int field, void* dst) {
+    if (c->N <= 0) return 0;
+    DevView d = sph_view(c);
+    hipLaunchKernelGGL(k_extract, dim3((c->N + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, field, c->color_cold, dst);
+    SPH_LAUNCH_CHECK(c);
+    return 0;
+}
+
+int sphk_insert(SphContext* c, int field, const void* src) {
+    if (c->N <= 0) return 0;
+    DevView d = sph_view(c);
+    hipLaunchKernelGGL(k_insert, dim3((c->N + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, field, c->x0_cold,
+                       c->color_cold, src);
+    SPH_LAUNCH_CHECK(c);
+    return 0;
+}
+
+int sphk_init_pid(SphContext* c) {
+    hipLaunchKernelGGL(k_init_pid, dim3((c->cap + TPB - 1) / TPB), dim3(TPB), 0, c->stream, c->aux[0], c->aux[1],
+                       c->cap);
+    SPH_LAUNCH_CHECK(c);
+    return 0;
+}
+
+int sphk_build_dyn_list(SphContext* c) {
+    SPH_HIP(c, hipMemsetAsync(c->dyn_count, 0, sizeof(int), c->stream));
+    if (c->N > 0) {
+        DevView d = sph_view(c);
+        hipLaunchKernelGGL(k_build_dyn_list, dim3((c->N + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, c->dyn_list,
+                           c->dyn_count);
+        SPH_LAUNCH_CHECK(c);
+    }
+    return 0;
+}

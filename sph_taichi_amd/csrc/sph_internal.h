@@ -1,0 +1,198 @@
+// sph_internal.h -- private to libsph_hip.so (gfx950 only).
+//
+// Data layout in HBM (all particle arrays are in the CURRENT cell-sorted order
+// unless marked "cold"):
+//   xm [cap] float4 = (x, y, z, m_V)                  hot, ping-pong through the sort
+//   vf [cap] float4 = (vx, vy, vz, bits(flags))       hot, ping-pong
+//   aux[cap] float4 = (m, density, pressure, bits(pid)) hot, ping-pong
+//   eos[cap] float4 = (p/rho^2, m/rho_raw, m, rho)    written by density+EOS, read by force
+//   acc[cap] float4 = (ax, ay, az, 0)
+//   key[cap] int    = grid_ids                        ping-pong
+//   x0_cold [3*cap] f32, color_cold [3*cap] i32       indexed by pid, never moved
+//   cell_end[G] int = inclusive prefix of the cell histogram (= the reference's
+//                     grid_particles_num after PrefixSumExecutor.run)
+// flags = material (bits 0..7) | is_dynamic (bit 8) | object_id (bits 9..31).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/sph_hip.h"
+
+#define SPH_MATERIAL_SOLID 0  // particle_system.py:30
+#define SPH_MATERIAL_FLUID 1  // particle_system.py:31
+#define SPH_MAX_TIMED_STEPS 128
+
+struct DevView {
+    int N, G;
+    int nx, ny, nz;
+    int ox, oy, oz;  // cell_origin (multi-GPU slabs)
+    float grid_size, h, d, d2, m_V0, rho0, stiffness, exponent, sigma, dt;
+    float gx, gy, gz;
+    float domx, domy, domz, pad;
+    float k_w, k_dw, visc_d_nu, visc_eps;
+    float w_zero, w_d;  // W(0), W(d)
+    float4* xm;
+    float4* vf;
+    float4* aux;
+    float4* eos;
+    float4* acc;
+    int* key;
+    int* cell_end;
+    const float* x0_cold;
+    float* rigid_rest_cm;
+};
+
+struct SphContext {
+    SphParams p;
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    int N;    // current particle count
+    int cap;  // capacity
+    int G;
+    int cur;  // which ping-pong set is current
+    float4* xm[2];
+    float4* vf[2];
+    float4* aux[2];
+    int* key[2];
+    float4* eos;
+    float4* acc;
+    float4* acc_tmp;
+    int* cell_end;     // [G+1]
+    int* rank_off;     // [cap] arbitrary intra-cell offset from the histogram atomics
+    int* idx_unstable; // [cap]
+    int* scan_sums;    // block sums for the scan
+    int scan_blocks;
+    float* x0_cold;    // [3*cap]
+    int* color_cold;   // [3*cap]
+    float* rigid_rest_cm;  // [n_objects*3]
+    int* dyn_list;     // [cap] sorted-order indices of dynamic rigid particles
+    int* dyn_count;    // device counter
+    int n_dyn_host;    // number of dynamic rigid particles (constant; counted at upload)
+    double* rigid_accum;  // [16] scratch: sum m, sum m x[3], A[9]
+    float* rigid_R;    // [12] cm[3] + R[9]
+    void* stage;       // upload/download staging, cap*16 bytes (>= G*4)
+    size_t stage_bytes;
+    bool have_keys, have_prefix, sorted;
+    // options
+    int opt_gather_impl, opt_timing, opt_fused, opt_brick_shape;
+    // timing
+    hipEvent_t ev[SPH_MAX_TIMED_STEPS][5];
+    int ev_used;
+    SphTimings tm;
+    char err[512];
+};
+
+DevView sph_view(const SphContext* c);
+int sph_fail(SphContext* c, int code, const char* what);
+
+#define SPH_HIP(ctx, expr)                                                        \
+    do {                                                                          \
+        hipError_t e__ = (expr);                                                  \
+        if (e__ != hipSuccess) {                                                  \
+            snprintf((ctx)->err, sizeof((ctx)->err), "%s: %s (%s:%d)", #expr,     \
+                     hipGetErrorString(e__), __FILE__, __LINE__);                 \
+            return (int)e__;                                                      \
+        }                                                                         \
+    } while (0)
+
+#define SPH_LAUNCH_CHECK(ctx) SPH_HIP(ctx, hipGetLastError())
+
+// ---- launch entry points implemented in the .hip files --------------------
+int sphk_hash_histogram(SphContext* c);
+int sphk_scan(SphContext* c);
+int sphk_sort_scatter(SphContext* c, bool sort_acc);
+int sphk_gather(SphContext* c, int mode);
+int sphk_eos(SphContext* c);
+int sphk_advect(SphContext* c, bool fused_fluid_walls);
+int sphk_enforce_boundary(SphContext* c, int particle_type);
+int sphk_rigid_com(SphContext* c, int object_id, bool to_rest);
+int sphk_rigid_solve(SphContext* c, int object_id);
+int sphk_extract(SphContext* c, int field, void* dst);
+int sphk_insert(SphContext* c, int field, const void* src);
+
+enum GatherMode {
+    GM_BVOL_STATIC = 0,
+    GM_BVOL_DYNAMIC = 1,
+    GM_DENSITY = 2,       // WCSPH.py:33-43 only
+    GM_DENSITY_EOS = 3,   // + EOS (WCSPH.py:74-76), eos record, acc init of solids (fused step)
+    GM_NONPRESSURE = 4,   // WCSPH.py:128-140
+    GM_PRESSURE = 5,      // WCSPH.py:77-85 (second loop; EOS done by sphk_eos)
+    GM_FORCE_FUSED = 6    // K6 + K7 in one sweep (needs GM_DENSITY_EOS before)
+};
+
+#ifdef __HIPCC__
+// ---------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int sph_flags_material(int f) { return f & 0xFF; }
+__device__ __forceinline__ int sph_flags_dynamic(int f) { return (f >> 8) & 1; }
+__device__ __forceinline__ int sph_flags_object(int f) { return (int)((unsigned)f >> 9); }
+__device__ __forceinline__ bool sph_is_fluid(int f) { return (f & 0xFF) == SPH_MATERIAL_FLUID; }
+__device__ __forceinline__ bool sph_is_static_rigid(int f) { return (f & 0x1FF) == 0; }
+__device__ __forceinline__ bool sph_is_dynamic_rigid(int f) { return (f & 0x1FF) == 0x100; }
+
+// particle_system.py:287-289 pos_to_index: (pos / grid_size).cast(int), f32
+// IEEE division (hipcc's default is the correctly rounded divide), truncation.
+// Out-of-domain coordinates are clamped (UB in the reference).
+__device__ __forceinline__ int sph_cell_coord(float p, float grid_size, int origin, int n) {
+    int c = (int)(p / grid_size) - origin;
+    c = c < 0 ? 0 : c;
+    c = c > n - 1 ? n - 1 : c;
+    return c;
+}
+// particle_system.py:292-294 flatten_grid_index (z fastest)
+__device__ __forceinline__ int sph_flatten(const DevView& d, int cx, int cy, int cz) {
+    return (cx * d.ny + cy) * d.nz + cz;
+}
+
+// sph_base.py:23-44 cubic_kernel
+__device__ __forceinline__ float sph_W(const DevView& d, float r_norm) {
+    float res = 0.0f;
+    const float q = r_norm / d.h;
+    if (q <= 1.0f) {
+        if (q <= 0.5f) {
+            const float q2 = q * q;
+            const float q3 = q2 * q;
+            res = d.k_w * (6.0f * q3 - 6.0f * q2 + 1.0f);
+        } else {
+            const float t = 1.0f - q;
+            res = d.k_w * 2.0f * (t * t * t);  // ti.pow(1-q, 3.0)
+        }
+    }
+    return res;
+}
+
+// sph_base.py:46-68 cubic_kernel_derivative; r_norm = |r| supplied by the caller
+__device__ __forceinline__ float3 sph_gradW(const DevView& d, float rx, float ry, float rz, float r_norm) {
+    float3 res = make_float3(0.0f, 0.0f, 0.0f);
+    const float q = r_norm / d.h;
+    if (r_norm > 1e-5f && q <= 1.0f) {
+        const float inv = r_norm * d.h;
+        float c;
+        if (q <= 0.5f) {
+            c = d.k_dw * q * (3.0f * q - 2.0f);
+        } else {
+            const float f = 1.0f - q;
+            c = d.k_dw * (-f * f);
+        }
+        res.x = c * (rx / inv);
+        res.y = c * (ry / inv);
+        res.z = c * (rz / inv);
+    }
+    return res;
+}
+
+// wave64 inclusive scan (the wavefront primitive replacing scan_single_buffer.py:4-29's
+// 32-lane shfl_up ladder)
+__device__ __forceinline__ int sph_wave_inclusive_scan(int v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int n = __shfl_up(v, off, 64);
+        if (lane >= off) v += n;
+    }
+    return v;
+}
+#endif  // __HIPCC__

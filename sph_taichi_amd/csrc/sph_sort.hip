@@ -1,0 +1,213 @@
+// sph_sort.hip -- K1..K3 of the hot path: grid hash + histogram, wave64 prefix
+// sum, STABLE counting sort.  Replaces particle_system.py:311-375 and
+// scan_single_buffer.py:44-146 (reference root).
+//
+// The reference ranks particles with atomic_sub inside a parallel loop
+// (particle_system.py:325-330); a serial run of that loop yields the stable
+// order (ascending previous index inside a cell).  We reproduce exactly that
+// order, deterministically, in three bandwidth-bound passes:
+//   hash_histogram : key[i] = cell(x_i); off[i] = arbitrary unique offset in
+//                    the cell (one returning atomic per RUN of equal cells in
+//                    a wave -- particles arrive almost sorted, so ~8x fewer
+//                    atomics than one per particle)
+//   scan           : cell_end = inclusive prefix (3 launches, wave64 shuffles)
+//   unstable_place : idx_unstable[start(c)+off[i]] = i
+//   stable_scatter : rank of i among its cell's members by previous index,
+//                    then move the 48-byte hot record (ping-pong, no copy-back)
+#include "sph_internal.h"
+
+#define TPB 256
+#define SCAN_IPT 8
+#define SCAN_TILE (TPB * SCAN_IPT)
+
+__global__ __launch_bounds__(TPB) void k_hash_histogram(DevView d, int* __restrict__ cell_cnt,
+                                                        int* __restrict__ rank_off) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int c = -1 - lane;  // inactive lanes get distinct sentinels
+    if (i < d.N) {
+        const float4 p = d.xm[i];
+        // particle_system.py:287-298 get_flatten_grid_index
+        const int cx = sph_cell_coord(p.x, d.grid_size, d.ox, d.nx);
+        const int cy = sph_cell_coord(p.y, d.grid_size, d.oy, d.ny);
+        const int cz = sph_cell_coord(p.z, d.grid_size, d.oz, d.nz);
+        c = sph_flatten(d, cx, cy, cz);
+        d.key[i] = c;  // particle_system.py:315
+    }
+    // run detection inside the wave (wavefront ballot primitive)
+    const int prev = __shfl_up(c, 1, 64);
+    const bool head = (lane == 0) || (prev != c);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long below = heads & (~0ull >> (63 - lane));  // heads at lanes <= lane
+    const int head_lane = 63 - __clzll(below);
+    const unsigned long long above = (head_lane == 63) ? 0ull : (heads >> (head_lane + 1));
+    const int run_len = above ? (__ffsll((long long)above)) : (64 - head_lane);
+    int base = 0;
+    if (head && c >= 0) base = atomicAdd(&cell_cnt[c], run_len);  // particle_system.py:316
+    base = __shfl(base, head_lane, 64);
+    if (i < d.N) rank_off[i] = base + (lane - head_lane);
+}
+
+// ---- scan: in-place inclusive i32 prefix sum over the (padded) cell array ----
+__device__ __forceinline__ int block_exclusive_offset(int thread_total, int* s_wave, int& block_total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int incl = sph_wave_inclusive_scan(thread_total, lane);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    int wave_off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < TPB / 64; ++w) {
+        const int s = s_wave[w];
+        if (w < wave) wave_off += s;
+        tot += s;
+    }
+    block_total = tot;
+    return wave_off + incl - thread_total;
+}
+
+__global__ __launch_bounds__(TPB) void k_scan_reduce(const int4* __restrict__ data, int* __restrict__ sums) {
+    __shared__ int s_wave[TPB / 64];
+    const int base = (blockIdx.x * TPB + threadIdx.x) * (SCAN_IPT / 4);
+    int t = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_IPT / 4; ++k) {
+        const int4 v = data[base + k];
+        t += v.x + v.y + v.z + v.w;
+    }
+    int tot;
+    (void)block_exclusive_offset(t, s_wave, tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+// one block: exclusive scan of the per-tile sums
+__global__ __launch_bounds__(1024) void k_scan_sums(int* __restrict__ sums, int n) {
+    __shared__ int s_wave[16];
+    __shared__ int s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n ? sums[i] : 0;
+        const int incl = sph_wave_inclusive_scan(v, lane);
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        int wave_off = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int s = s_wave[w];
+            if (w < wave) wave_off += s;
+            tot += s;
+        }
+        const int carry = s_carry;
+        if (i < n) sums[i] = carry + wave_off + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = carry + tot;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_scan_apply(int4* __restrict__ data, const int* __restrict__ sums) {
+    __shared__ int s_wave[TPB / 64];
+    const int base = (blockIdx.x * TPB + threadIdx.x) * (SCAN_IPT / 4);
+    int4 v[SCAN_IPT / 4];
+    int t = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_IPT / 4; ++k) {
+        v[k] = data[base + k];
+        t += v[k].x + v[k].y + v[k].z + v[k].w;
+    }
+    int tot;
+    int run = sums[blockIdx.x] + block_exclusive_offset(t, s_wave, tot);
+#pragma unroll
+    for (int k = 0; k < SCAN_IPT / 4; ++k) {
+        run += v[k].x; v[k].x = run;
+        run += v[k].y; v[k].y = run;
+        run += v[k].z; v[k].z = run;
+        run += v[k].w; v[k].w = run;
+        data[base + k] = v[k];
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_unstable_place(DevView d, const int* __restrict__ rank_off,
+                                                        int* __restrict__ idx_unstable) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= d.N) return;
+    const int c = d.key[i];
+    const int b = c > 0 ? d.cell_end[c - 1] : 0;  // particle_system.py:327-329 base_offset
+    idx_unstable[b + rank_off[i]] = i;
+}
+
+template <bool SORT_ACC>
+__global__ __launch_bounds__(TPB) void k_stable_scatter(DevView d, const int* __restrict__ idx_unstable,
+                                                        float4* __restrict__ xm_out, float4* __restrict__ vf_out,
+                                                        float4* __restrict__ aux_out, int* __restrict__ key_out,
+                                                        float4* __restrict__ acc_out, int* __restrict__ dyn_list,
+                                                        int* __restrict__ dyn_count) {
+    const int s = blockIdx.x * TPB + threadIdx.x;
+    if (s >= d.N) return;
+    const int i = idx_unstable[s];
+    const int c = d.key[i];
+    const int b = c > 0 ? d.cell_end[c - 1] : 0;
+    const int e = d.cell_end[c];
+    int rank = 0;
+    for (int t = b; t < e; ++t) rank += (idx_unstable[t] < i) ? 1 : 0;
+    const int dst = b + rank;  // == grid_ids_new[i] of a serial run (particle_system.py:330)
+    const float4 xm = d.xm[i];
+    const float4 vf = d.vf[i];
+    const float4 aux = d.aux[i];
+    xm_out[dst] = xm;
+    vf_out[dst] = vf;
+    aux_out[dst] = aux;
+    key_out[dst] = c;
+    if (SORT_ACC) acc_out[dst] = d.acc[i];
+    if (sph_is_dynamic_rigid(__float_as_int(vf.w))) dyn_list[atomicAdd(dyn_count, 1)] = dst;
+}
+
+// ---------------------------------------------------------------------------
+int sphk_hash_histogram(SphContext* c) {
+    const int Gpad = c->scan_blocks * SCAN_TILE;
+    SPH_HIP(c, hipMemsetAsync(c->cell_end, 0, sizeof(int) * (size_t)Gpad, c->stream));
+    if (c->N > 0) {
+        DevView d = sph_view(c);
+        hipLaunchKernelGGL(k_hash_histogram, dim3((c->N + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, c->cell_end,
+                           c->rank_off);
+        SPH_LAUNCH_CHECK(c);
+    }
+    return 0;
+}
+
+int sphk_scan(SphContext* c) {
+    const int nb = c->scan_blocks;
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(TPB), 0, c->stream, (const int4*)c->cell_end, c->scan_sums);
+    SPH_LAUNCH_CHECK(c);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, c->stream, c->scan_sums, nb);
+    SPH_LAUNCH_CHECK(c);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(TPB), 0, c->stream, (int4*)c->cell_end, c->scan_sums);
+    SPH_LAUNCH_CHECK(c);
+    return 0;
+}
+
+int sphk_sort_scatter(SphContext* c, bool sort_acc) {
+    if (c->N <= 0) return 0;
+    DevView d = sph_view(c);
+    const int nb = (c->N + TPB - 1) / TPB;
+    const int o = c->cur ^ 1;
+    SPH_HIP(c, hipMemsetAsync(c->dyn_count, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_unstable_place, dim3(nb), dim3(TPB), 0, c->stream, d, c->rank_off, c->idx_unstable);
+    SPH_LAUNCH_CHECK(c);
+    if (sort_acc)
+        hipLaunchKernelGGL(k_stable_scatter<true>, dim3(nb), dim3(TPB), 0, c->stream, d, c->idx_unstable, c->xm[o],
+                           c->vf[o], c->aux[o], c->key[o], c->acc_tmp, c->dyn_list, c->dyn_count);
+    else
+        hipLaunchKernelGGL(k_stable_scatter<false>, dim3(nb), dim3(TPB), 0, c->stream, d, c->idx_unstable, c->xm[o],
+                           c->vf[o], c->aux[o], c->key[o], c->acc_tmp, c->dyn_list, c->dyn_count);
+    SPH_LAUNCH_CHECK(c);
+    c->cur = o;
+    if (sort_acc) {
+        float4* t = c->acc;
+        c->acc = c->acc_tmp;
+        c->acc_tmp = t;
+    }
+    return 0;
+}

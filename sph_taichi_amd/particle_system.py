@@ -1,0 +1,207 @@
+"""ParticleSystem with the reference's attribute / method surface
+(/root/reference/particle_system.py:10-495), backed by a HIP context.
+
+What stays on the host (NumPy): scene ingestion (sph_taichi_amd/scene.py).
+What moved to the GPU: every per-particle array (owned by libsph_hip's context,
+exposed here as DeviceField objects with the reference's names) and the
+neighbour-structure kernels update_grid_id / prefix sum / counting_sort.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib, scene as _scene
+from .config_builder import SimConfig
+from .field import DeviceField, HostScalar
+
+
+class ParticleSystem:
+    def __init__(self, config: SimConfig, GGUI=False, device: int = 0, stream=None, scene_dir: str | None = None,
+                 verbose: bool = False):
+        self.cfg = config
+        self.GGUI = GGUI
+        sc = _scene.build_scene(config, base_dir=scene_dir, verbose=verbose)
+        g = sc.geom
+        self._scene = sc
+        # ---- scalars, same names as the reference (particle_system.py:17-46) ----
+        self.domain_start = g.domain_start
+        self.domain_end = g.domain_end
+        self.domain_size = g.domain_size
+        self.dim = g.dim
+        self.simulation_method = config.get_cfg("simulationMethod")
+        self.material_solid = _scene.MATERIAL_SOLID
+        self.material_fluid = _scene.MATERIAL_FLUID
+        self.particle_radius = g.particle_radius
+        self.particle_diameter = g.particle_diameter
+        self.support_radius = g.support_radius
+        self.m_V0 = g.m_V0
+        self.grid_size = g.grid_size
+        self.grid_num = g.grid_num
+        self.padding = g.padding
+        self.object_collection = sc.object_collection
+        self.object_id_rigid_body = sc.object_id_rigid_body
+        self.fluid_particle_num = sc.fluid_particle_num
+        self.solid_particle_num = sc.solid_particle_num
+        self.particle_max_num = sc.particle_max_num
+        self.num_rigid_bodies = sc.num_rigid_bodies
+        self.particle_num = HostScalar(0, int)
+        if verbose:
+            print("grid size: ", self.grid_num)
+            print(f"Current particle num: {self.particle_num[None]}, Particle max num: {self.particle_max_num}")
+
+        # ---- device context (replaces the ti.field allocations of :91-145) ----
+        self._lib = _lib.load()
+        self._params = self._make_params(sc)
+        ctx = C.c_void_p()
+        stream_ptr = C.c_void_p(int(stream)) if stream else None
+        rc = self._lib.sph_create(C.byref(self._params), int(device), stream_ptr, C.byref(ctx))
+        if rc != 0:
+            msg = self._lib.sph_last_error(None)
+            raise _lib.SphError(f"sph_create failed (rc={rc}): {msg.decode() if msg else ''}")
+        self._ctx = ctx
+        n = lambda: self.particle_max_num
+        F = _lib
+        mk = lambda fid, dt, vec=0, w=True, name="": DeviceField(self, fid, dt, n, vec, w, name)
+        self.object_id = mk(F.F_OBJECT_ID, np.int32, name="object_id")
+        self.x = mk(F.F_X, np.float32, 3, name="x")
+        self.x_0 = mk(F.F_X_0, np.float32, 3, name="x_0")
+        self.v = mk(F.F_V, np.float32, 3, name="v")
+        self.acceleration = mk(F.F_ACCELERATION, np.float32, 3, name="acceleration")
+        self.m_V = mk(F.F_M_V, np.float32, name="m_V")
+        self.m = mk(F.F_M, np.float32, name="m")
+        self.density = mk(F.F_DENSITY, np.float32, name="density")
+        self.pressure = mk(F.F_PRESSURE, np.float32, name="pressure")
+        self.material = mk(F.F_MATERIAL, np.int32, name="material")
+        self.color = mk(F.F_COLOR, np.int32, 3, name="color")
+        self.is_dynamic = mk(F.F_IS_DYNAMIC, np.int32, name="is_dynamic")
+        self.grid_ids = mk(F.F_GRID_IDS, np.int32, w=False, name="grid_ids")
+        self.pid = mk(F.F_PID, np.int32, w=False, name="pid")
+        G = int(np.prod(self.grid_num))
+        self.grid_particles_num = DeviceField(self, F.F_GRID_PARTICLES_NUM, np.int32, lambda: G, 0, False,
+                                              "grid_particles_num")
+        if self.num_rigid_bodies > 0:
+            self.rigid_rest_cm = DeviceField(self, F.F_RIGID_REST_CM, np.float32, lambda: sc.n_objects, 3, True,
+                                             "rigid_rest_cm")
+        self.x_vis_buffer = None
+        if self.GGUI:
+            self.x_vis_buffer = np.zeros((self.particle_max_num, 3), dtype=np.float32)
+            self.color_vis_buffer = np.zeros((self.particle_max_num, 3), dtype=np.float32)
+
+        # ---- upload the initial particles (the reference's _add_particles, :260-284) ----
+        for name, arr in sc.arrays.items():
+            getattr(self, name).from_numpy(arr)
+        self.particle_num[None] = self.particle_max_num
+
+    # ------------------------------------------------------------------
+    def _make_params(self, sc, solver=None):
+        g = sc.geom
+        cfg = self.cfg
+        p = _lib.SphParams()
+        p.n_particles = sc.particle_max_num
+        p.capacity = max(sc.particle_max_num, 1)
+        p.grid_num = (C.c_int32 * 3)(*[int(v) for v in g.grid_num])
+        p.cell_origin = (C.c_int32 * 3)(0, 0, 0)
+        p.n_objects = sc.n_objects
+        p.grid_size = g.grid_size
+        p.support_radius = g.support_radius
+        p.particle_diameter = g.particle_diameter
+        p.m_V0 = g.m_V0
+        viscosity = getattr(solver, "viscosity", 0.01)                      # sph_base.py:15
+        p.density_0 = getattr(solver, "density_0", cfg.get_cfg("density0") or 1000.0)
+        p.stiffness = getattr(solver, "stiffness", cfg.get_cfg("stiffness") or 50000.0)
+        p.exponent = getattr(solver, "exponent", cfg.get_cfg("exponent") or 7.0)
+        p.viscosity = viscosity
+        p.surface_tension = getattr(solver, "surface_tension", 0.01)       # WCSPH.py:15
+        p.dt = solver.dt[None] if solver is not None else (cfg.get_cfg("timeStepSize") or 1e-4)
+        grav = getattr(solver, "g", None)
+        if grav is None:
+            grav = cfg.get_cfg("gravitation") or [0.0, -9.81, 0.0]
+        p.g = (C.c_float * 3)(*[float(v) for v in grav])
+        p.domain_size = (C.c_float * 3)(*[float(v) for v in g.domain_size])
+        p.padding = g.padding
+        p.wall_hi = (C.c_float * 3)(*[float(v) - g.padding for v in g.domain_size])   # f64 fold, then f32
+        kc = _scene.kernel_constants(g.support_radius, viscosity, g.dim)
+        p.k_w, p.k_dw, p.visc_d_nu, p.visc_eps = kc["k_w"], kc["k_dw"], kc["visc_d_nu"], kc["visc_eps"]
+        return p
+
+    def _push_solver_params(self, solver):
+        self._params = self._make_params(self._scene, solver)
+        self._call("sph_set_params", C.byref(self._params))
+
+    def _call(self, name, *args):
+        rc = getattr(self._lib, name)(self._ctx, *args)
+        _lib.check(self._lib, self._ctx, rc, name)
+
+    def set_option(self, option: int, value: int):
+        self._call("sph_set_option", int(option), int(value))
+
+    def sync(self):
+        self._call("sph_sync")
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.sph_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- reference methods ------------------------------------------------
+    def build_solver(self):
+        """particle_system.py:214-221."""
+        solver_type = self.cfg.get_cfg("simulationMethod")
+        if solver_type == 0:
+            from .WCSPH import WCSPHSolver
+            return WCSPHSolver(self)
+        raise NotImplementedError(f"Solver type {solver_type} has not been implemented.")
+
+    def update_grid_id(self):
+        """particle_system.py:311-320."""
+        self._call("sph_update_grid_id")
+
+    def prefix_sum(self):
+        """self.prefix_sum_executor.run(self.grid_particles_num)  (particle_system.py:374)."""
+        self._call("sph_prefix_sum")
+
+    def counting_sort(self):
+        """particle_system.py:322-369."""
+        self._call("sph_counting_sort")
+
+    def initialize_particle_system(self):
+        """particle_system.py:372-375."""
+        self.update_grid_id()
+        self.prefix_sum()
+        self.counting_sort()
+
+    def add_cube(self, *a, **k):
+        raise NotImplementedError("particles can only be created from the scene file "
+                                  "(the reference has no emitters either, particle_system.py:85-86)")
+
+    add_particles = add_cube
+
+    def compute_cube_particle_num(self, start, end):
+        return _scene.compute_cube_particle_num(start, end, self.particle_diameter, self.dim)
+
+    def dump(self, obj_id):
+        """particle_system.py:409-418."""
+        mask = (self.object_id.to_numpy() == obj_id).nonzero()
+        return {"position": self.x.to_numpy()[mask], "velocity": self.v.to_numpy()[mask]}
+
+    def copy_to_vis_buffer(self, invisible_objects=[]):
+        """particle_system.py:392-407 (host copy; there is no GGUI here)."""
+        assert self.GGUI
+        oid = self.object_id.to_numpy()
+        x = self.x.to_numpy()
+        col = self.color.to_numpy()
+        if len(invisible_objects) != 0:
+            self.x_vis_buffer[:] = 0.0
+            self.color_vis_buffer[:] = 0.0
+        vis = ~np.isin(oid, list(invisible_objects)) & np.isin(oid, list(self.object_collection.keys()))
+        self.x_vis_buffer[vis] = x[vis]
+        self.color_vis_buffer[vis] = col[vis] / 255.0

@@ -1,0 +1,92 @@
+"""Small synthetic scenes shared by the tests (scene dicts in the reference's
+JSON schema) + helpers that build the oracle / the HIP system
+from the same host arrays."""
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+
+from sph_taichi_amd.config_builder import SimConfig
+from sph_taichi_amd import scene as scene_mod
+
+BASE_CFG = {
+    "domainStart": [0.0, 0.0, 0.0], "domainEnd": [1.0, 1.2, 0.8], "particleRadius": 0.01,
+    "numberOfStepsPerRenderUpdate": 1, "density0": 1000, "simulationMethod": 0,
+    "gravitation": [0.0, -9.81, 0.0], "timeStepSize": 0.0004, "stiffness": 50000, "exponent": 7,
+    "boundaryHandlingMethod": 0, "exportFrame": False, "exportPly": False, "exportObj": False,
+}
+
+
+def _block(oid, start, end, velocity=(0.0, 0.0, 0.0), density=1000.0, color=(50, 100, 200), **kw):
+    b = {"objectId": oid, "start": list(start), "end": list(end), "translation": [0.0, 0.0, 0.0],
+         "scale": [1, 1, 1], "velocity": list(velocity), "density": density, "color": list(color)}
+    b.update(kw)
+    return b
+
+
+def lattice_end(start, counts, d=0.02):
+    """end such that np.arange(start, end, d) has exactly `counts` entries."""
+    return [s + (c - 0.5) * d for s, c in zip(start, counts)]
+
+
+def fluid_only(counts=(10, 12, 8), start=(0.1, 0.1, 0.1), velocity=(0.0, -1.0, 0.0), domain_end=(1.0, 1.2, 0.8)):
+    cfg = copy.deepcopy(BASE_CFG)
+    cfg["domainEnd"] = list(domain_end)
+    return {"Configuration": cfg, "FluidBlocks": [_block(0, start, lattice_end(start, counts), velocity)]}
+
+
+def fluid_with_rigid_blocks(fluid_counts=(10, 10, 8), static_counts=(14, 2, 12), dyn_counts=(4, 4, 4)):
+    """Fluid block resting on a static slab with a dynamic cube falling into it:
+    exercises K4 (both), Akinci boundary pressure, two-way coupling and K9."""
+    cfg = copy.deepcopy(BASE_CFG)
+    static_start = (0.08, 0.06, 0.08)
+    fluid_start = (0.12, 0.06 + static_counts[1] * 0.02 + 0.01, 0.12)
+    dyn_start = (0.16, fluid_start[1] + fluid_counts[1] * 0.02, 0.16)  # one spacing above the fluid surface
+    return {
+        "Configuration": cfg,
+        "FluidBlocks": [_block(0, fluid_start, lattice_end(fluid_start, fluid_counts), (0.0, -0.5, 0.0))],
+        "RigidBlocks": [
+            _block(1, static_start, lattice_end(static_start, static_counts), density=1000.0, isDynamic=False,
+                   color=(255, 255, 255)),
+            _block(2, dyn_start, lattice_end(dyn_start, dyn_counts), velocity=(0.0, -2.0, 0.0), density=800.0,
+                   isDynamic=True, color=(255, 100, 50)),
+        ],
+    }
+
+
+def jitter(scene, amplitude=0.1, seed=0):
+    """positions += U(-a d, a d): breaks lattice ties for sort / force tests."""
+    rng = np.random.default_rng(seed)
+    d = scene.geom.particle_diameter
+    x = scene.arrays["x"]
+    x += rng.uniform(-amplitude * d, amplitude * d, size=x.shape).astype(np.float32)
+    scene.arrays["x_0"] = x.copy()
+    return scene
+
+
+def build(scene_dict):
+    cfg = SimConfig(config=copy.deepcopy(scene_dict))
+    return cfg, scene_mod.build_scene(cfg)
+
+
+def solver_params(cfg, scene):
+    g = scene.geom
+    return dict(particle_radius=g.particle_radius, domain_size=list(g.domain_size), density_0=cfg.get_cfg("density0"),
+                stiffness=cfg.get_cfg("stiffness"), exponent=cfg.get_cfg("exponent"),
+                dt=cfg.get_cfg("timeStepSize"), g=cfg.get_cfg("gravitation"))
+
+
+def make_oracle(cfg, scene, omp_threads=1):
+    from oracle.oracle import Oracle
+    # RigidBlocks are not in object_id_rigid_body in the reference (particle_system.py:171-188):
+    # only RigidBodies are shape-matched.  Tests that want a shape-matched block pass ids explicitly.
+    return Oracle(solver_params(cfg, scene), scene.arrays, n_objects=max(scene.n_objects, 1),
+                  rigid_body_ids=sorted(scene.object_id_rigid_body), dynamic_ids=sorted(scene.dynamic_rigid_ids),
+                  omp_threads=omp_threads)
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))

@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py -- WCSPH steps/s + ms/step breakdown (sort / neighbour / force) on MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one WCSPHSolver.step() (SPHBase.step(), reference sph_base.py:263-271)
+over the synthetic uniform box of BASELINE.md (C3': 246x74x96 = 1,747,584 fluid
+particles in the armadillo scene's (5,3,2) domain; BASELINE.json's metric is quoted
+at 1.74 M particles).  Inputs are resident in HBM before the timed region.
+
+`value` = particle-steps/s / 1,747,584, i.e. "steps/s at 1.74 M particles": at
+N = 1 it is exactly the job's steps/s; at N > 1 (x-slab sharding, every rank owns
+one 1.75 M slab: weak scaling) it is the whole-job aggregate.
+
+The JSON line also carries
+  roofline     : the dominant kernel (fused force sweep) -- algorithmic bytes per
+                 launch (60*N + 4*G) / its mean launch time from HIP
+                 events on the kernel's own stream, against the 8 TB/s HBM peak;
+  cpu_baseline : the CPU oracle (oracle/sph_oracle.c, "port" of the reference
+                 algorithm with OpenMP) timed on this box's host cores on a
+                 bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+REF_PARTICLES = 1_747_584          # C3' 
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+CFG = {
+    "domainStart": [0.0, 0.0, 0.0], "domainEnd": [5.0, 3.0, 2.0], "particleRadius": 0.01,
+    "numberOfStepsPerRenderUpdate": 1, "density0": 1000, "simulationMethod": 0,
+    "gravitation": [0.0, -9.81, 0.0], "timeStepSize": 0.0004, "stiffness": 50000, "exponent": 7,
+    "boundaryHandlingMethod": 0, "exportFrame": False, "exportPly": False, "exportObj": False,
+}
+
+WORKLOADS = {
+    # name: (domainEnd, fluid lattice counts, lower corner)
+    "c3p_uniform_1.75M": ([5.0, 3.0, 2.0], (246, 74, 96), (0.04, 0.04, 0.04)),
+    "c1_dambreak_262k": ([3.2, 2.0, 1.4], (64, 64, 64), (0.04, 0.04, 0.04)),
+    "c0_dragon_fluid_423k": ([5.0, 3.0, 2.0], (55, 140, 55), (0.3, 0.1, 0.7)),
+}
+
+
+def scene_dict(workload: str):
+    dom, counts, corner = WORKLOADS[workload]
+    cfg = copy.deepcopy(CFG)
+    cfg["domainEnd"] = dom
+    d = 2 * cfg["particleRadius"]
+    end = [c + (n - 0.5) * d for c, n in zip(corner, counts)]
+    vel = [0.0, -1.0, 0.0] if workload.startswith("c0") else [0.0, 0.0, 0.0]
+    return {"Configuration": cfg,
+            "FluidBlocks": [{"objectId": 0, "start": list(corner), "end": end, "translation": [0.0, 0.0, 0.0],
+                             "scale": [1, 1, 1], "velocity": vel, "density": 1000.0, "color": [50, 100, 200]}]}
+
+
+def cpu_baseline(sd, sample_steps: int):
+    """Time the CPU oracle on a bounded sample of the same workload (rank 0, N=1 only)."""
+    from oracle.oracle import Oracle, max_threads
+    from sph_taichi_amd.config_builder import SimConfig
+    from sph_taichi_amd import scene as scene_mod
+    cfg = SimConfig(config=copy.deepcopy(sd))
+    sc = scene_mod.build_scene(cfg)
+    g = sc.geom
+    params = dict(particle_radius=g.particle_radius, domain_size=list(g.domain_size),
+                  density_0=cfg.get_cfg("density0"), stiffness=cfg.get_cfg("stiffness"),
+                  exponent=cfg.get_cfg("exponent"), dt=cfg.get_cfg("timeStepSize"), g=cfg.get_cfg("gravitation"))
+    threads = max_threads()
+    o = Oracle(params, sc.arrays, n_objects=1, omp_threads=threads)
+    o.initialize()
+    o.step(1)                                   # warm-up (page faults, first sort)
+    t0 = time.perf_counter()
+    ms = o.step(sample_steps)
+    dt = time.perf_counter() - t0
+    n = sc.particle_max_num
+    return {"value": round(sample_steps / dt * n / REF_PARTICLES, 4), "unit": "steps/s at 1.74M particles",
+            "cores": threads, "kind": "port",
+            "sample": f"{sample_steps} steps of the same {n}-particle workload after 1 warm-up step, "
+                      f"oracle/sph_oracle.c with {threads} OpenMP threads",
+            "ms_per_step": round(dt / sample_steps * 1e3, 2),
+            "phase_ms": {k: round(v / sample_steps, 2) for k, v in zip(("sort", "neighbour", "force", "integrate"), ms)}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c3p_uniform_1.75M", choices=sorted(WORKLOADS))
+    ap.add_argument("--gather-impl", type=int, default=1)
+    ap.add_argument("--brick-shape", type=int, default=0)
+    ap.add_argument("--fused", type=int, default=1)
+    ap.add_argument("--cpu-steps", type=int, default=3, help="CPU-oracle sample size (0 = skip the baseline leg)")
+    ap.add_argument("--sweep", action="store_true", help="also time every gather variant (stderr table)")
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from sph_taichi_amd.distributed import run_slab_bench
+        line = run_slab_bench(args, rank, world, local_rank)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        dist.destroy_process_group()
+        return
+
+    from sph_taichi_amd import ParticleSystem, SimConfig, _lib
+    sd = scene_dict(args.workload)
+    ps = ParticleSystem(SimConfig(config=copy.deepcopy(sd)), device=local_rank)
+    solver = ps.build_solver()
+    N = ps.particle_max_num
+    G = int(ps.grid_num[0] * ps.grid_num[1] * ps.grid_num[2])
+
+    def run(impl, shape, fused, steps, warmup):
+        ps.set_option(_lib.OPT_GATHER_IMPL, impl)
+        ps.set_option(_lib.OPT_BRICK_SHAPE, shape)
+        ps.set_option(_lib.OPT_FUSED_STEP, fused)
+        ps.set_option(_lib.OPT_TIMING, 0)
+        solver.step(warmup)
+        ps.set_option(_lib.OPT_TIMING, 1)
+        ps._call("sph_reset_timings")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        solver.step(steps)
+        ps.sync()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        tm = _lib.SphTimings()
+        ps._call("sph_get_timings", tm)
+        return dt, tm
+
+    solver.initialize()
+    if args.sweep:
+        for impl, shape, fused in [(0, 0, 1), (1, 0, 1), (1, 1, 1), (1, 2, 1), (1, 3, 1), (1, 0, 0)]:
+            dt, tm = run(impl, shape, fused, max(args.steps // 4, 10), 5)
+            k = max(tm.steps, 1)
+            print(f"[sweep] impl={impl} shape={shape} fused={fused}: {dt / max(args.steps // 4, 10) * 1e3:.3f} ms/step "
+                  f"sort={tm.sort_ms / k:.3f} neigh={tm.neighbour_ms / k:.3f} force={tm.force_ms / k:.3f} "
+                  f"integ={tm.integrate_ms / k:.3f}", file=sys.stderr, flush=True)
+
+    dt, tm = run(args.gather_impl, args.brick_shape, args.fused, args.steps, args.warmup)
+    k = max(int(tm.steps), 1)
+    ms_per_step = dt / args.steps * 1e3
+    steps_per_s = args.steps / dt
+    value = steps_per_s * N / REF_PARTICLES
+    force_ms = tm.force_ms / k
+    alg_bytes = 60.0 * N + 4.0 * G                      # fused force sweep, per launch
+    achieved = alg_bytes / (force_ms * 1e-3) / 1e9 if force_ms > 0 else 0.0
+    line = {
+        "metric": "WCSPH steps/sec at 1.74 M particles (+ ms/step breakdown sort/neighbour/force)",
+        "value": round(value, 3), "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": args.workload, "particles": N, "cells": G, "dt": CFG["timeStepSize"],
+                   "gather_impl": args.gather_impl, "brick_shape": args.brick_shape, "fused": args.fused,
+                   "parallelism": "1 GPU"},
+        "breakdown_ms": {"sort": round(tm.sort_ms / k, 4), "neighbour": round(tm.neighbour_ms / k, 4),
+                         "force": round(force_ms, 4), "integrate": round(tm.integrate_ms / k, 4),
+                         "sum_of_phases": round(tm.total_ms / k, 4)},
+        "steps_per_s_job": round(steps_per_s, 3),
+        "roofline": {"kernel": "k_gather_brick<GM_FORCE_FUSED>" if args.gather_impl else "k_gather_simple<GM_FORCE_FUSED>",
+                     "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(force_ms, 4)},
+    }
+    # secondary: whole-step algorithmic bytes (360 N + 20 G) against the same peak
+    step_bytes = 360.0 * N + 20.0 * G
+    line["roofline_step"] = {"alg_bytes": step_bytes, "achieved_GBs": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 2),
+                             "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+    ps.close()
+    if args.cpu_steps > 0:
+        line["cpu_baseline"] = cpu_baseline(sd, args.cpu_steps)
+    else:
+        line["cpu_baseline"] = None
+    print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

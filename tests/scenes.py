@@ -90,3 +90,26 @@ def rel_l2(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def make_ps(scene_dict, arrays=None, gather_impl=1, brick_shape=0, fused=1):
+    """HIP-backed ParticleSystem + solver for a scene dict; `arrays` (e.g. a
+    jittered / permuted copy) overrides the scene's initial particle arrays."""
+    from sph_taichi_amd import ParticleSystem, _lib
+    ps = ParticleSystem(SimConfig(config=copy.deepcopy(scene_dict)))
+    if arrays is not None:
+        for k, v in arrays.items():
+            if k in scene_mod.ARRAY_SPECS:
+                getattr(ps, k).from_numpy(v)
+    ps.set_option(_lib.OPT_GATHER_IMPL, gather_impl)
+    ps.set_option(_lib.OPT_BRICK_SHAPE, brick_shape)
+    ps.set_option(_lib.OPT_FUSED_STEP, fused)
+    solver = ps.build_solver()
+    return ps, solver
+
+
+def ps_by_pid(ps, name):
+    arr = getattr(ps, name).to_numpy()
+    out = np.empty_like(arr)
+    out[ps.pid.to_numpy()] = arr
+    return out

@@ -22,7 +22,7 @@ DevView sph_view(const SphContext* c) {
     d.N = c->N; d.G = c->G;
     d.nx = p.grid_num[0]; d.ny = p.grid_num[1]; d.nz = p.grid_num[2];
     d.ox = p.cell_origin[0]; d.oy = p.cell_origin[1]; d.oz = p.cell_origin[2];
-    d.grid_size = p.grid_size; d.h = p.support_radius; d.d = p.particle_diameter;
+    d.grid_size = p.grid_size; d.h = p.support_radius; d.inv_h = 1.0f / p.support_radius; d.d = p.particle_diameter;
     d.d2 = p.particle_diameter * p.particle_diameter;  // WCSPH.py:96
     d.m_V0 = p.m_V0; d.rho0 = p.density_0; d.stiffness = p.stiffness; d.exponent = p.exponent;
     d.sigma = p.surface_tension; d.dt = p.dt;
@@ -117,6 +117,8 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     rc = rc ? rc : alloc_dev(c, (void**)&c->rank_off, cap * 4);
     rc = rc ? rc : alloc_dev(c, (void**)&c->idx_unstable, cap * 4);
     rc = rc ? rc : alloc_dev(c, (void**)&c->scan_sums, (size_t)(c->scan_blocks + 1) * 4);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->glist, cap * 2 * SPH_GLIST_ROWS);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->gcnt, cap);
     rc = rc ? rc : alloc_dev(c, (void**)&c->x0_cold, cap * 12);
     rc = rc ? rc : alloc_dev(c, (void**)&c->color_cold, cap * 12);
     rc = rc ? rc : alloc_dev(c, (void**)&c->rigid_rest_cm, (size_t)(params->n_objects > 0 ? params->n_objects : 1) * 12);
@@ -147,7 +149,7 @@ int32_t sph_destroy(SphContext* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->xm[0], c->xm[1], c->vf[0], c->vf[1], c->aux[0], c->aux[1], c->key[0], c->key[1], c->eos, c->acc,
                     c->acc_tmp, c->cell_end, c->rank_off, c->idx_unstable, c->scan_sums, c->x0_cold, c->color_cold,
-                    c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->rigid_accum, c->rigid_R, c->stage};
+                    c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->rigid_accum, c->rigid_R, c->stage, c->glist, c->gcnt};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < SPH_MAX_TIMED_STEPS; ++s)
         for (int k = 0; k < 5; ++k) if (c->ev[s][k]) (void)hipEventDestroy(c->ev[s][k]);

@@ -33,6 +33,7 @@ struct Target {
     float ax, ay, az;      // non-pressure accumulator (starts at g)
     float px, py, pz;      // pressure accumulator
     float st_c;            // surface_tension / m_i
+    float dpj_solid;       // p_i / rho0^2 (WCSPH.py:60)
 };
 
 template <int MODE>
@@ -72,66 +73,89 @@ __device__ __forceinline__ void target_init(const DevView& d, Target& t, int i, 
     t.s0 = 0.0f;
     t.ax = d.gx; t.ay = d.gy; t.az = d.gz;  // WCSPH.py:135-136 d_v = g
     t.px = t.py = t.pz = 0.0f;
-    t.m = t.rho = t.p = t.dpi = t.st_c = 0.0f;
+    t.m = t.rho = t.p = t.dpi = t.st_c = t.dpj_solid = 0.0f;
     if (MODE == GM_NONPRESSURE || MODE == GM_PRESSURE) {
         const float4 aux = d.aux[i];
         t.m = aux.x; t.rho = aux.y; t.p = aux.z;
         t.dpi = aux.z / (aux.y * aux.y);  // WCSPH.py:49
         t.st_c = d.sigma / aux.x;         // WCSPH.py:100
+        t.dpj_solid = aux.z / (d.rho0 * d.rho0);
     }
     if (MODE == GM_FORCE_FUSED) {
         const float4 e = d.eos[i];
         t.dpi = e.x; t.m = e.z; t.rho = e.w;
         t.p = e.x * (e.w * e.w);
         t.st_c = d.sigma / e.z;
+        t.dpj_solid = t.p / (d.rho0 * d.rho0);
     }
     if (MODE == GM_BVOL_STATIC || MODE == GM_BVOL_DYNAMIC) t.s0 = d.w_zero;  // sph_base.py:95, 110
+}
+
+// Fast reciprocal / rsqrt (v_rsq_f32 / v_rcp_f32, ~1 ulp).  The reference's
+// r.norm(), r / (r_norm * h), x / y become r2 * rsq(r2), r * (rsq * 1/h), x * rcp(y):
+// same formulas, a few ulp apart, far inside the 1e-4 position budget; hipcc's
+// correctly-rounded div/sqrt expansions (~10 VALU each) were the dominant cost.
+__device__ __forceinline__ float sph_rsq(float x) { return x > 0.0f ? __builtin_amdgcn_rsqf(x) : 0.0f; }
+__device__ __forceinline__ float sph_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// sph_base.py:23-44 cubic_kernel as a function of q = r/h (q <= 1 is guaranteed by the caller's r < h)
+__device__ __forceinline__ float sph_W_q(const DevView& d, float q) {
+    const float t = 1.0f - q;
+    const float inner = d.k_w * ((6.0f * q - 6.0f) * q * q + 1.0f);
+    const float outer = d.k_w * 2.0f * (t * t * t);
+    return q <= 0.5f ? inner : outer;
+}
+// sph_base.py:46-68 cubic_kernel_derivative = coef * (rx, ry, rz); coef folds grad_q = r / (|r| h)
+__device__ __forceinline__ float sph_gradW_coef(const DevView& d, float q, float r_norm, float rinv) {
+    const float f = 1.0f - q;
+    const float c = q <= 0.5f ? d.k_dw * q * (3.0f * q - 2.0f) : d.k_dw * (-f * f);
+    return r_norm > 1e-5f ? c * (rinv * d.inv_h) : 0.0f;
 }
 
 // One accepted pair (i != j, r_norm = |x_i - x_j| < h).  gj = global (sorted)
 // index of j, needed only for the coupling scatter.
 template <int MODE>
 __device__ __forceinline__ void pair_physics(const DevView& d, Target& t, float rx, float ry, float rz, float r2,
-                                             float r_norm, const float4 A, const float4 B, const float4 Cc, int gj) {
+                                             float r_norm, float rinv, const float4 A, const float4 B,
+                                             const float4 Cc, int gj) {
+    const float q = r_norm * d.inv_h;
     if (MODE == GM_DENSITY || MODE == GM_DENSITY_EOS) {
         // WCSPH.py:19-30: fluid and solid neighbours add m_V_j * W identically
-        t.s0 += A.w * sph_W(d, r_norm);
+        t.s0 += A.w * sph_W_q(d, q);
         return;
     }
     const int fj = __float_as_int(B.w);
     if (MODE == GM_BVOL_STATIC || MODE == GM_BVOL_DYNAMIC) {
-        if (sph_flags_material(fj) == SPH_MATERIAL_SOLID) t.s0 += sph_W(d, r_norm);  // sph_base.py:100-103
+        if (sph_flags_material(fj) == SPH_MATERIAL_SOLID) t.s0 += sph_W_q(d, q);  // sph_base.py:100-103
         return;
     }
     const bool j_fluid = sph_is_fluid(fj);
+    const float gc = sph_gradW_coef(d, q, r_norm, rinv);
     if (MODE == GM_NONPRESSURE || MODE == GM_FORCE_FUSED) {
         if (j_fluid) {
             // surface tension  WCSPH.py:93-102
-            const float w = (r2 > d.d2) ? sph_W(d, r_norm) : d.w_d;
-            const float c = t.st_c * Cc.z;
-            t.ax -= c * rx * w; t.ay -= c * ry * w; t.az -= c * rz * w;
+            const float w = (r2 > d.d2) ? sph_W_q(d, q) : d.w_d;
+            const float c = t.st_c * Cc.z * w;
             // viscosity  WCSPH.py:105-116
             const float v_xy = (t.vx - B.x) * rx + (t.vy - B.y) * ry + (t.vz - B.z) * rz;
-            const float3 gw = sph_gradW(d, rx, ry, rz, r_norm);
-            const float cv = d.visc_d_nu * Cc.y * v_xy / (r_norm * r_norm + d.visc_eps);
-            t.ax += cv * gw.x; t.ay += cv * gw.y; t.az += cv * gw.z;
+            const float cv = d.visc_d_nu * Cc.y * v_xy * sph_rcp(r2 + d.visc_eps) * gc;
+            const float k = cv - c;
+            t.ax += k * rx; t.ay += k * ry; t.az += k * rz;
         }
         // solid neighbour: boundary_viscosity = 0.0 => contributes exactly 0 (WCSPH.py:117-125)
     }
     if (MODE == GM_PRESSURE || MODE == GM_FORCE_FUSED) {
-        const float3 gw = sph_gradW(d, rx, ry, rz, r_norm);
         if (j_fluid) {
             // WCSPH.py:51-57
-            const float c = -d.rho0 * A.w * (t.dpi + Cc.x);
-            t.px += c * gw.x; t.py += c * gw.y; t.pz += c * gw.z;
+            const float c = -d.rho0 * A.w * (t.dpi + Cc.x) * gc;
+            t.px += c * rx; t.py += c * ry; t.pz += c * rz;
         } else if (sph_flags_material(fj) == SPH_MATERIAL_SOLID) {
             // WCSPH.py:58-68 (Akinci 2012 boundary pressure + two-way coupling)
-            const float dpj = t.p / (d.rho0 * d.rho0);
-            const float c = -d.rho0 * A.w * (t.dpi + dpj);
-            const float fx = c * gw.x, fy = c * gw.y, fz = c * gw.z;
+            const float c = -d.rho0 * A.w * (t.dpi + t.dpj_solid) * gc;
+            const float fx = c * rx, fy = c * ry, fz = c * rz;
             t.px += fx; t.py += fy; t.pz += fz;
             if (sph_is_dynamic_rigid(fj)) {
-                const float sc = d.rho0 / Cc.w;
+                const float sc = d.rho0 * sph_rcp(Cc.w);
                 float* a = reinterpret_cast<float*>(&d.acc[gj]);
                 unsafeAtomicAdd(a + 0, -fx * sc);
                 unsafeAtomicAdd(a + 1, -fy * sc);
@@ -229,12 +253,13 @@ __device__ __forceinline__ void gather_walk_global(const DevView& d, Target& t, 
                 const float4 A = d.xm[j];
                 const float rx = t.x - A.x, ry = t.y - A.y, rz = t.z - A.z;
                 const float r2 = rx * rx + ry * ry + rz * rz;
-                const float rn = sqrtf(r2);
+                const float rinv = sph_rsq(r2);
+                const float rn = r2 * rinv;
                 if (rn < d.h) {  // particle_system.py:385
                     float4 B = make_float4(0.f, 0.f, 0.f, 0.f), Cc = B;
                     if (mode_needs_B<MODE>()) B = d.vf[j];
                     if (mode_needs_C<MODE>()) Cc = load_C_global<MODE>(d, j);
-                    pair_physics<MODE>(d, t, rx, ry, rz, r2, rn, A, B, Cc, j);
+                    pair_physics<MODE>(d, t, rx, ry, rz, r2, rn, rinv, A, B, Cc, j);
                 }
             }
         }
@@ -259,42 +284,58 @@ __global__ __launch_bounds__(TPB) void k_gather_simple(DevView d, const int* __r
 // ---------------------------------------------------------------------------
 // v1: LDS-staged cell bricks
 // ---------------------------------------------------------------------------
-template <int BX_, int BY_, int BZ_, int CAP_, int LISTCAP_, bool BC_LDS_>
+// LDS holds the shell's records as two float2 arrays, (x,y) and (z,m_V): with 8
+// particles per cell the slots of lanes in different cells differ by multiples
+// of 8, which is a 2-way bank conflict for ds_read_b128's interleaved lane
+// groups but conflict-free for ds_read_b64.
+// List entries are u16: (shell column << 11) | LDS slot, so CAP <= 2048 and
+// NCOL <= 32; the global index of a slot is sColG[col] + slot - sColS[col].
+// In the fused step the density sweep writes each target's list to HBM
+// (glist[k*cap + i], gcnt[i]) and the force sweep -- same positions, same
+// brick layout -- reads it back instead of filtering again.
+#define SPH_CNT_WALK 255  // gcnt sentinel: this target must take the exact global cell walk
+
+template <int MODE>
+__host__ __device__ constexpr bool mode_writes_list() { return MODE == GM_DENSITY_EOS; }
+template <int MODE>
+__host__ __device__ constexpr bool mode_reads_list() { return MODE == GM_FORCE_FUSED; }
+
+template <int BX_, int BY_, int BZ_, int CAP_, int LISTCAP_>
 struct BrickCfg {
     static constexpr int BX = BX_, BY = BY_, BZ = BZ_, CAP = CAP_, LISTCAP = LISTCAP_;
-    static constexpr bool BC_LDS = BC_LDS_;
-    static constexpr int NCOL = (BX + 2) * (BY + 2);  // <= 64 (one wave builds the column table)
-    static constexpr int NZS = BZ + 3;                // cell-end entries per column
+    static constexpr int NCOL = (BX + 2) * (BY + 2);
+    static constexpr int NZS = BZ + 3;  // cell-end entries per column (start + BZ+2 ends)
+    static constexpr int PER = (CAP + TPB - 1) / TPB;  // staged records per lane
     // LDS carve (bytes, every offset a multiple of 16)
-    static constexpr int OFF_A = 0;
-    static constexpr int OFF_B = OFF_A + CAP * 16;
-    static constexpr int OFF_C = OFF_B + (BC_LDS ? CAP * 16 : 0);
-    static constexpr int OFF_G = OFF_C + (BC_LDS ? CAP * 16 : 0);  // global index of each staged candidate
-    static constexpr int OFF_LIST = OFF_G + CAP * 4;
-    static constexpr int OFF_CE = OFF_LIST + LISTCAP * TPB * 2;
+    static constexpr int OFF_XY = 0;
+    static constexpr int OFF_ZW = OFF_XY + CAP * 8;
+    static constexpr int OFF_CE = OFF_ZW + CAP * 8;
     static constexpr int OFF_COLG = OFF_CE + ((NCOL * NZS * 4 + 15) / 16) * 16;
     static constexpr int OFF_COLS = OFF_COLG + 64 * 4;
     static constexpr int OFF_TG = OFF_COLS + 80 * 4;
     static constexpr int OFF_TOFF = OFF_TG + 64 * 4;
-    static constexpr int BYTES = OFF_TOFF + 80 * 4;
-    static_assert(NCOL <= 64, "column table is built by one wave");
-    static_assert(CAP <= 65535, "LDS indices are stored as u16");
+    static constexpr int OFF_LIST = OFF_TOFF + 80 * 4;
+    static constexpr int BYTES_NOLIST = OFF_LIST;
+    static constexpr int BYTES_LIST = OFF_LIST + (LISTCAP + 1) * TPB * 2;  // +1 guard row for overflowing appends
+    static_assert(NCOL <= 32, "column id must fit 5 bits of a list entry");
+    static_assert(CAP <= 2048, "LDS slot must fit 11 bits of a list entry");
+    static_assert(LISTCAP < SPH_CNT_WALK, "gcnt is a byte");
+    static_assert(BYTES_LIST <= 54608, "three workgroups per CU (160 KiB LDS)");
 };
 
 template <int MODE, class CFG>
 __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nby, int nbz, int nbricks,
-                                                      int bricks_per_xcd) {
+                                                      int bricks_per_xcd, unsigned short* __restrict__ glist,
+                                                      unsigned char* __restrict__ gcnt, int cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* sA = reinterpret_cast<float4*>(smem + CFG::OFF_A);
-    float4* sB = reinterpret_cast<float4*>(smem + CFG::OFF_B);
-    float4* sC = reinterpret_cast<float4*>(smem + CFG::OFF_C);
-    int* sG = reinterpret_cast<int*>(smem + CFG::OFF_G);
-    unsigned short* sList = reinterpret_cast<unsigned short*>(smem + CFG::OFF_LIST);
-    int* sCE = reinterpret_cast<int*>(smem + CFG::OFF_CE);      // [NCOL][NZS], LDS-relative candidate index
+    float2* sXY = reinterpret_cast<float2*>(smem + CFG::OFF_XY);
+    float2* sZW = reinterpret_cast<float2*>(smem + CFG::OFF_ZW);
+    int* sCE = reinterpret_cast<int*>(smem + CFG::OFF_CE);      // [NCOL][NZS] raw cell_end values of the shell
     int* sColG = reinterpret_cast<int*>(smem + CFG::OFF_COLG);  // global start of the column segment
-    int* sColS = reinterpret_cast<int*>(smem + CFG::OFF_COLS);  // LDS start of the column segment (+ total)
+    int* sColS = reinterpret_cast<int*>(smem + CFG::OFF_COLS);  // LDS start of the column segment (+ total at [64])
     int* sTG = reinterpret_cast<int*>(smem + CFG::OFF_TG);      // global start of the column's targets
-    int* sTOff = reinterpret_cast<int*>(smem + CFG::OFF_TOFF);  // target-number start of the column (+ total)
+    int* sTOff = reinterpret_cast<int*>(smem + CFG::OFF_TOFF);  // target-number start of the column (+ total at [64])
+    unsigned short* sList = reinterpret_cast<unsigned short*>(smem + CFG::OFF_LIST);  // absent when the list is read from HBM
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -314,20 +355,22 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
     const int ncols = (sx1 - sx0 + 1) * ncy;
     const int nzs = sz1 - sz0 + 1;
 
-    // ---- step A: column table (wave 0) ----
+    // ---- step A: per shell column, the cell-end table and the segment scan (wave 0) ----
     if (wave == 0) {
         int len = 0, tlen = 0, gstart = 0, tstart = 0;
         if (lane < ncols) {
             const int ix = sx0 + lane / ncy, iy = sy0 + lane % ncy;
-            const int flo = sph_flatten(d, ix, iy, sz0);
-            const int fhi = sph_flatten(d, ix, iy, sz1);
-            gstart = d.cell_end[flo > 0 ? flo - 1 : 0];  // particle_system.py:384 (cell 0 quirk kept)
-            len = d.cell_end[fhi] - gstart;
+            const int base = sph_flatten(d, ix, iy, sz0);
+            gstart = d.cell_end[base > 0 ? base - 1 : 0];  // particle_system.py:384 max(0, idx-1): cell 0 quirk kept
+            sCE[lane * CFG::NZS] = gstart;
+#pragma unroll
+            for (int k = 1; k < CFG::NZS; ++k)
+                if (k <= nzs) sCE[lane * CFG::NZS + k] = d.cell_end[base + k - 1];
+            len = sCE[lane * CFG::NZS + nzs] - gstart;
             if (ix >= cx0 && ix < cx1 && iy >= cy0 && iy < cy1) {
-                const int tlo = sph_flatten(d, ix, iy, cz0);
-                const int thi = sph_flatten(d, ix, iy, cz1 - 1);
-                tstart = tlo > 0 ? d.cell_end[tlo - 1] : 0;
-                tlen = d.cell_end[thi] - tstart;
+                // targets: cells cz0 .. cz1-1 of this column (true start, also for flat cell 0)
+                tstart = (base + (cz0 - sz0) > 0) ? sCE[lane * CFG::NZS + (cz0 - sz0)] : 0;
+                tlen = sCE[lane * CFG::NZS + (cz1 - sz0)] - tstart;
             }
         }
         const int incl = sph_wave_inclusive_scan(len, lane);
@@ -344,26 +387,24 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
     if (T == 0) return;
     const bool overflow = total > CFG::CAP;
 
+    // ---- step B: stage the shell's (x, y, z, m_V) records; all loads of a lane in flight together ----
     if (!overflow) {
-        // cell-end table, LDS-relative: sCE[col][0] = segment start, sCE[col][k] = end of cell sz0+k-1
-        for (int e = tid; e < ncols * (nzs + 1); e += TPB) {
-            const int col = e / (nzs + 1), k = e % (nzs + 1);
-            int v;
-            if (k == 0) v = sColS[col];
-            else {
-                const int ix = sx0 + col / ncy, iy = sy0 + col % ncy;
-                v = d.cell_end[sph_flatten(d, ix, iy, sz0 + k - 1)] - sColG[col] + sColS[col];
-            }
-            sCE[col * CFG::NZS + k] = v;
+        float4 buf[CFG::PER];
+#pragma unroll
+        for (int u = 0; u < CFG::PER; ++u) {
+            const int idx = min(tid + u * TPB, total - 1);  // clamped: the load is always valid
+            int col = 0;  // largest col with sColS[col] <= idx (entries >= ncols hold `total`)
+#pragma unroll
+            for (int step = 16; step > 0; step >>= 1)
+                if (sColS[col + step] <= idx) col += step;
+            buf[u] = d.xm[sColG[col] + (idx - sColS[col])];
         }
-        // ---- step B: stage candidate records, one column segment per wave pass ----
-        for (int col = wave; col < ncols; col += TPB / 64) {
-            const int g0 = sColG[col], s0 = sColS[col], len = sColS[col + 1 < ncols ? col + 1 : 64] - s0;
-            for (int k = lane; k < len; k += 64) {
-                sA[s0 + k] = d.xm[g0 + k];
-                sG[s0 + k] = g0 + k;
-                if (CFG::BC_LDS && mode_needs_B<MODE>()) sB[s0 + k] = d.vf[g0 + k];
-                if (CFG::BC_LDS && mode_needs_C<MODE>()) sC[s0 + k] = load_C_global<MODE>(d, g0 + k);
+#pragma unroll
+        for (int u = 0; u < CFG::PER; ++u) {
+            const int idx = tid + u * TPB;
+            if (idx < total) {
+                sXY[idx] = make_float2(buf[u].x, buf[u].y);
+                sZW[idx] = make_float2(buf[u].z, buf[u].w);
             }
         }
     }
@@ -372,69 +413,139 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
     // ---- step C: targets ----
     for (int tn = tid; tn < T; tn += TPB) {
         int col = 0;
-        while (tn >= sTOff[col + 1 < 64 ? col + 1 : 64] && col < ncols - 1) ++col;
+#pragma unroll
+        for (int step = 16; step > 0; step >>= 1)
+            if (sTOff[col + step] <= tn) col += step;
         const int gi = sTG[col] + (tn - sTOff[col]);
         Target t;
         const float4 Ai = d.xm[gi];
         const float4 Bi = d.vf[gi];
         target_init<MODE>(d, t, gi, Ai, Bi);
         const bool g = target_gathers<MODE>(t.flags);
-        if (g && overflow) gather_walk_global<MODE>(d, t, gi);
-        if (g && !overflow) {
+        bool walk = g && overflow;
+        int cnt = 0;
+        const int li = sColS[col] + (gi - sColG[col]);  // own LDS slot
+        if (g && !overflow && !mode_reads_list<MODE>()) {
             const int ix = sx0 + col / ncy, iy = sy0 + col % ncy;
             const int cz = d.key[gi] % d.nz;
-            const int li = sColS[col] + (gi - sColG[col]);  // own LDS slot
-            const int klo = (cz > 0 ? cz - 1 : 0) - sz0;            // first cell of the z-run, shell-relative
+            const int klo = (cz > 0 ? cz - 1 : 0) - sz0;  // first cell of the z-run, shell-relative
             const int khi = (cz < d.nz - 1 ? cz + 1 : d.nz - 1) - sz0;
             const float h2p = d.h * d.h * 1.000001f;  // superset filter; the exact r < h test is in phase 2
-            int cnt = 0;
-            // phase 1: filter candidates into the private index list
+            // point-to-cell distances for culling (exact: a culled cell cannot hold a particle within h;
+            // 0.1% slack on h^2 covers the ulp-level mismatch between float cell hashing and cell geometry)
+            const float h2c = d.h * d.h * 1.001f;
+            // offsets inside the own cell, clamped so that a particle hashed into a boundary cell from
+            // outside the domain only makes the culling more conservative
+            const float ux = fminf(fmaxf(t.x - (float)(ix + d.ox) * d.grid_size, 0.0f), d.grid_size),
+                        uy = fminf(fmaxf(t.y - (float)(iy + d.oy) * d.grid_size, 0.0f), d.grid_size),
+                        uz = fminf(fmaxf(t.z - (float)(cz + d.oz) * d.grid_size, 0.0f), d.grid_size);
+            const float gzlo = uz * uz, gzhi = (d.grid_size - uz) * (d.grid_size - uz);
+            char* lp = reinterpret_cast<char*>(sList) + tid * 2;
+            char* const lp0 = lp;
+            char* const lp_guard = lp + CFG::LISTCAP * TPB * 2;
+            // phase 1: filter the 9 column runs into the private index list (4 LDS slots in flight)
             for (int dx = -1; dx <= 1; ++dx) {
                 const int nx = ix + dx;
                 if (nx < 0 || nx >= d.nx) continue;
+                const float gx = dx == 0 ? 0.0f : (dx > 0 ? d.grid_size - ux : ux);
                 for (int dy = -1; dy <= 1; ++dy) {
                     const int ny = iy + dy;
                     if (ny < 0 || ny >= d.ny) continue;
+                    const float gy = dy == 0 ? 0.0f : (dy > 0 ? d.grid_size - uy : uy);
+                    const float gxy2 = gx * gx + gy * gy;
+                    if (gxy2 > h2c) continue;  // whole column out of reach
                     const int ncol = (nx - sx0) * ncy + (ny - sy0);
-                    const int lo = sCE[ncol * CFG::NZS + klo];
-                    const int hi = sCE[ncol * CFG::NZS + khi + 1];
-                    for (int j = lo; j < hi; ++j) {
-                        const float4 A = sA[j];
-                        const float rx = t.x - A.x, ry = t.y - A.y, rz = t.z - A.z;
-                        const float r2 = rx * rx + ry * ry + rz * rz;
-                        if (r2 < h2p && j != li) {
-                            if (cnt < CFG::LISTCAP) {
-                                sList[cnt * TPB + tid] = (unsigned short)j;
-                                ++cnt;
-                            } else {  // list full (extreme compression): do the pair now
-                                const float rn = sqrtf(r2);
-                                if (rn < d.h) {
-                                    const int gj = sG[j];
-                                    float4 B = make_float4(0.f, 0.f, 0.f, 0.f), Cc = B;
-                                    if (mode_needs_B<MODE>()) B = CFG::BC_LDS ? sB[j] : d.vf[gj];
-                                    if (mode_needs_C<MODE>()) Cc = CFG::BC_LDS ? sC[j] : load_C_global<MODE>(d, gj);
-                                    pair_physics<MODE>(d, t, rx, ry, rz, r2, rn, A, B, Cc, gj);
-                                }
-                            }
-                        }
+                    const int rel = sColS[ncol] - sColG[ncol];
+                    // trim the lower / upper cell of the z-run when it is out of reach
+                    const int kl = klo + ((cz > 0 && gxy2 + gzlo > h2c) ? 1 : 0);
+                    const int kh = khi - ((cz < d.nz - 1 && gxy2 + gzhi > h2c) ? 1 : 0);
+                    const int lo = sCE[ncol * CFG::NZS + kl] + rel;
+                    const int hi = sCE[ncol * CFG::NZS + kh + 1] + rel;
+                    const unsigned tag = (unsigned)ncol << 11;
+#define SPH_FILTER(XY, ZW, jj)                                                       \
+    {                                                                                \
+        const float rx_ = t.x - (XY).x, ry_ = t.y - (XY).y, rz_ = t.z - (ZW).x;      \
+        const float r2_ = rx_ * rx_ + ry_ * ry_ + rz_ * rz_;                         \
+        if (r2_ < h2p) {                                                             \
+            *reinterpret_cast<unsigned short*>(lp < lp_guard ? lp : lp_guard) =      \
+                (unsigned short)(tag | (unsigned)(jj));                              \
+            lp += TPB * 2;                                                           \
+        }                                                                            \
+    }
+                    int j = lo;
+                    for (; j + 4 <= hi; j += 4) {
+                        const float2 p0 = sXY[j], p1 = sXY[j + 1], p2 = sXY[j + 2], p3 = sXY[j + 3];
+                        const float2 q0 = sZW[j], q1 = sZW[j + 1], q2 = sZW[j + 2], q3 = sZW[j + 3];
+                        SPH_FILTER(p0, q0, j) SPH_FILTER(p1, q1, j + 1) SPH_FILTER(p2, q2, j + 2)
+                        SPH_FILTER(p3, q3, j + 3)
                     }
+                    for (; j < hi; ++j) {
+                        const float2 p0 = sXY[j];
+                        const float2 q0 = sZW[j];
+                        SPH_FILTER(p0, q0, j)
+                    }
+#undef SPH_FILTER
                 }
             }
-            // phase 2: pair physics over the list
+            cnt = (int)(lp - lp0) / (TPB * 2);
+            if (cnt > CFG::LISTCAP) walk = true;  // list overflow (extreme compression): exact slow path
+        }
+        if (mode_reads_list<MODE>() && g && !overflow) {
+            cnt = gcnt[gi];
+            if (cnt == SPH_CNT_WALK) { walk = true; cnt = 0; }
+        }
+        if (mode_writes_list<MODE>() && g) {
+            gcnt[gi] = (unsigned char)(walk ? SPH_CNT_WALK : cnt);
+            if (!walk)
+                for (int k = 0; k < cnt; ++k) glist[(size_t)k * cap + gi] = sList[k * TPB + tid];
+        }
+        if (g && !walk) {
+            // phase 2: pair physics over the list; the next entry's records are prefetched
+            unsigned e1 = 0, e2 = 0;  // entries k+1 and k+2
+            if (mode_reads_list<MODE>()) {
+                if (cnt > 0) e1 = glist[gi];
+                if (cnt > 1) e2 = glist[(size_t)cap + gi];
+            } else {
+                if (cnt > 0) e1 = sList[tid];
+                if (cnt > 1) e2 = sList[TPB + tid];
+            }
+            float2 XYn = make_float2(0.f, 0.f), ZWn = XYn;
+            float4 Bn = make_float4(0.f, 0.f, 0.f, 0.f), Cn = Bn;
+            int gn = 0, jn = -1;
+            if (cnt > 0) {
+                jn = e1 & 2047;
+                const int c2 = e1 >> 11;
+                XYn = sXY[jn]; ZWn = sZW[jn];
+                gn = sColG[c2] + (jn - sColS[c2]);
+                if (mode_needs_B<MODE>()) Bn = d.vf[gn];
+                if (mode_needs_C<MODE>()) Cn = load_C_global<MODE>(d, gn);
+            }
             for (int k = 0; k < cnt; ++k) {
-                const int j = sList[k * TPB + tid];
-                const float4 A = sA[j];
-                const float rx = t.x - A.x, ry = t.y - A.y, rz = t.z - A.z;
-                const float r2 = rx * rx + ry * ry + rz * rz;
-                const float rn = sqrtf(r2);
-                if (rn < d.h) {  // particle_system.py:385
-                    const int gj = sG[j];
-                    float4 B = make_float4(0.f, 0.f, 0.f, 0.f), Cc = B;
-                    if (mode_needs_B<MODE>()) B = CFG::BC_LDS ? sB[j] : d.vf[gj];
-                    if (mode_needs_C<MODE>()) Cc = CFG::BC_LDS ? sC[j] : load_C_global<MODE>(d, gj);
-                    pair_physics<MODE>(d, t, rx, ry, rz, r2, rn, A, B, Cc, gj);
+                const float2 XY = XYn, ZW = ZWn;
+                const float4 B = Bn, Cc = Cn;
+                const int gj = gn, j = jn;
+                if (k + 1 < cnt) {
+                    jn = e2 & 2047;
+                    const int c2 = e2 >> 11;
+                    XYn = sXY[jn]; ZWn = sZW[jn];
+                    gn = sColG[c2] + (jn - sColS[c2]);
+                    if (mode_needs_B<MODE>()) Bn = d.vf[gn];
+                    if (mode_needs_C<MODE>()) Cn = load_C_global<MODE>(d, gn);
+                    if (k + 2 < cnt)
+                        e2 = mode_reads_list<MODE>() ? (unsigned)glist[(size_t)(k + 2) * cap + gi]
+                                                     : (unsigned)sList[(k + 2) * TPB + tid];
                 }
+                const float rx = t.x - XY.x, ry = t.y - XY.y, rz = t.z - ZW.x;
+                const float r2 = rx * rx + ry * ry + rz * rz;
+                const float rinv = sph_rsq(r2);
+                const float rn = r2 * rinv;
+                if (rn < d.h && j != li)  // particle_system.py:385
+                    pair_physics<MODE>(d, t, rx, ry, rz, r2, rn, rinv, make_float4(XY.x, XY.y, ZW.x, ZW.y), B, Cc, gj);
             }
+        }
+        if (walk) {
+            target_init<MODE>(d, t, gi, Ai, Bi);
+            gather_walk_global<MODE>(d, t, gi);
         }
         target_finish<MODE>(d, t, gi, g);
     }
@@ -454,10 +565,10 @@ __global__ __launch_bounds__(TPB) void k_eos(DevView d) {
 // ---------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------
-typedef BrickCfg<2, 2, 8, 2048, 48, false> Cfg0;  // 2x2x8 cells, A in LDS, B/C via L2   (~61 KB)
-typedef BrickCfg<2, 2, 8, 1792, 48, true> Cfg1;   // 2x2x8 cells, A/B/C in LDS           (~120 KB)
-typedef BrickCfg<4, 2, 4, 2048, 48, false> Cfg2;  // 4x2x4 cells, A in LDS
-typedef BrickCfg<4, 4, 4, 2816, 48, false> Cfg3;  // 4x4x4 cells, A in LDS (two target rounds)
+typedef BrickCfg<4, 2, 4, 1664, 47> Cfg0;  // 4x2x4 cells: 1152 candidates / 256 targets at rest
+typedef BrickCfg<2, 2, 8, 1664, 47> Cfg1;  // 2x2x8 cells: 1280 candidates / 256 targets at rest
+typedef BrickCfg<2, 4, 4, 1664, 47> Cfg2;  // 2x4x4 cells
+typedef BrickCfg<2, 2, 4, 1664, 47> Cfg3;  // 2x2x4 cells:  768 candidates / 128 targets at rest
 
 template <int MODE>
 static int launch_simple(SphContext* c, const int* list, int n) {
@@ -475,14 +586,15 @@ static int launch_brick_cfg(SphContext* c) {
               nbz = (d.nz + CFG::BZ - 1) / CFG::BZ;
     const int nbricks = nbx * nby * nbz;
     const int per_xcd = (nbricks + 7) / 8;
+    const int bytes = mode_reads_list<MODE>() ? CFG::BYTES_NOLIST : CFG::BYTES_LIST;
     static bool attr_set = false;
     if (!attr_set) {
         SPH_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gather_brick<MODE, CFG>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, CFG::BYTES));
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gather_brick<MODE, CFG>), dim3(per_xcd * 8), dim3(TPB), CFG::BYTES, c->stream, d, nbx, nby,
-                       nbz, nbricks, per_xcd);
+    hipLaunchKernelGGL((k_gather_brick<MODE, CFG>), dim3(per_xcd * 8), dim3(TPB), bytes, c->stream, d, nbx, nby, nbz,
+                       nbricks, per_xcd, c->glist, c->gcnt, c->cap);
     SPH_LAUNCH_CHECK(c);
     return 0;
 }

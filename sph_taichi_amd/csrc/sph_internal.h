@@ -23,12 +23,13 @@
 #define SPH_MATERIAL_SOLID 0  // particle_system.py:30
 #define SPH_MATERIAL_FLUID 1  // particle_system.py:31
 #define SPH_MAX_TIMED_STEPS 128
+#define SPH_GLIST_ROWS 48
 
 struct DevView {
     int N, G;
     int nx, ny, nz;
     int ox, oy, oz;  // cell_origin (multi-GPU slabs)
-    float grid_size, h, d, d2, m_V0, rho0, stiffness, exponent, sigma, dt;
+    float grid_size, h, inv_h, d, d2, m_V0, rho0, stiffness, exponent, sigma, dt;
     float gx, gy, gz;
     float domx, domy, domz, pad;
     float k_w, k_dw, visc_d_nu, visc_eps;
@@ -64,6 +65,8 @@ struct SphContext {
     int* rank_off;     // [cap] arbitrary intra-cell offset from the histogram atomics
     int* idx_unstable; // [cap]
     int* scan_sums;    // block sums for the scan
+    unsigned short* glist;  // [SPH_GLIST_ROWS * cap] neighbour lists handed from the density to the force sweep
+    unsigned char* gcnt;    // [cap] list lengths (255 = take the global cell walk)
     int scan_blocks;
     float* x0_cold;    // [3*cap]
     int* color_cold;   // [3*cap]

@@ -112,10 +112,16 @@ def main():
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # SPH_DIST_BACKEND=gloo lets several ranks share one GPU (how the N>1 path is exercised on a 1-GPU box)
+    backend = os.environ.get("SPH_DIST_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
         from sph_taichi_amd.distributed import run_slab_bench
         line = run_slab_bench(args, rank, world, local_rank)
         if rank == 0:

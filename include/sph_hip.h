@@ -47,6 +47,7 @@ typedef struct SphParams {
     int32_t grid_num[3];        /* LOCAL grid dims               particle_system.py:44 */
     int32_t cell_origin[3];     /* global cell coord of local cell (0,0,0); 0 on one GPU */
     int32_t n_objects;          /* len(rigid_rest_cm)            particle_system.py:93 */
+    int32_t cold_capacity;      /* rows of the pid-indexed x_0 / color store; 0 = capacity (slabs: global N) */
     float grid_size;            /* = support_radius              particle_system.py:43 */
     float support_radius;       /* 4 r                           particle_system.py:37 */
     float particle_diameter;    /* 2 r                           particle_system.py:36 */
@@ -84,7 +85,7 @@ enum SphField {
     SPH_F_IS_DYNAMIC = 11,        /* i32 [N]   */
     SPH_F_GRID_IDS = 12,          /* i32 [N]   particle_system.py:138 (download only) */
     SPH_F_GRID_PARTICLES_NUM = 13,/* i32 [G]   particle_system.py:96  (download only) */
-    SPH_F_PID = 14,               /* i32 [N]   persistent id = index at upload time (download only) */
+    SPH_F_PID = 14,               /* i32 [N]   persistent id (default: index at creation); < cold_capacity */
     SPH_F_RIGID_REST_CM = 15,     /* f32 [n_objects,3]  particle_system.py:93 */
     SPH_F_COUNT_ = 16
 };
@@ -103,7 +104,9 @@ enum SphOption {
     SPH_OPT_GATHER_IMPL = 0,
     SPH_OPT_TIMING = 1,        /* 1 = record per-phase HIP events inside sph_step */
     SPH_OPT_FUSED_STEP = 2,    /* 1 (default) = sph_step uses the fused density+EOS / force kernels */
-    SPH_OPT_BRICK_SHAPE = 3    /* index into the compiled brick-shape table */
+    SPH_OPT_BRICK_SHAPE = 3,   /* index into the compiled brick-shape table */
+    SPH_OPT_NO_DYNAMIC_SOLIDS = 4 /* 1 = the caller guarantees no dynamic solid particle exists (slab ranks
+                                  cannot know this locally); skips the per-step device count */
 };
 
 /* ms accumulated by sph_step since the last sph_reset_timings (HIP events on
@@ -163,6 +166,29 @@ int32_t sph_step(SphContext* ctx, int32_t n_steps, const int32_t* dynamic_ids, i
 int32_t sph_sync(SphContext* ctx);
 int32_t sph_get_timings(SphContext* ctx, SphTimings* out);
 int32_t sph_reset_timings(SphContext* ctx);
+
+/* --- multi-GPU slab support (no reference counterpart) -------------
+ * Cells are flattened x-slowest (particle_system.py:294), so after the sort every
+ * set of x-layers is ONE contiguous index range.  A slab rank exchanges such ranges
+ * with its x-neighbours as packed records (48 B/particle: `count` xm float4s, then
+ * `count` vf float4s, then `count` aux float4s) through device buffers it owns
+ * (torch tensors + torch.distributed/RCCL on the host side). */
+#define SPH_RECORD_BYTES 48
+int32_t sph_get_particle_count(SphContext* ctx, int32_t* n);
+/* out[k] = number of particles in local x-layers < layers[k] (valid after
+ * sph_prefix_sum / the sort).  Synchronises. */
+int32_t sph_layer_offsets(SphContext* ctx, const int32_t* layers, int32_t n, int32_t* out);
+/* Keep only [first, first+count) of the current order as the particle set (drops
+ * ghosts); must be followed by a sort before any sweep. */
+int32_t sph_select_range(SphContext* ctx, int32_t first, int32_t count);
+int32_t sph_pack_range(SphContext* ctx, int32_t first, int32_t count, void* device_dst);
+/* Append `count` packed records after the current particles (count += n). */
+int32_t sph_append_records(SphContext* ctx, const void* device_src, int32_t count);
+/* The sort of sph_step (no acceleration permutation): hash + scan + scatter. */
+int32_t sph_sort(SphContext* ctx);
+/* One step's sweeps without the sort: boundary volume, density+EOS, force, advect +
+ * fluid walls (the slab driver sorts and exchanges halos itself). */
+int32_t sph_sweeps(SphContext* ctx);
 
 #ifdef __cplusplus
 }

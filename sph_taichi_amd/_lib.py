@@ -18,7 +18,7 @@ class SphParams(C.Structure):
     """Mirror of `struct SphParams` (include/sph_hip.h)."""
     _fields_ = [
         ("n_particles", C.c_int32), ("capacity", C.c_int32), ("grid_num", _I3), ("cell_origin", _I3),
-        ("n_objects", C.c_int32),
+        ("n_objects", C.c_int32), ("cold_capacity", C.c_int32),
         ("grid_size", C.c_float), ("support_radius", C.c_float), ("particle_diameter", C.c_float),
         ("m_V0", C.c_float), ("density_0", C.c_float), ("stiffness", C.c_float), ("exponent", C.c_float),
         ("viscosity", C.c_float), ("surface_tension", C.c_float), ("dt", C.c_float),
@@ -37,7 +37,7 @@ class SphTimings(C.Structure):
 F_OBJECT_ID, F_X, F_X_0, F_V, F_ACCELERATION, F_M_V, F_M, F_DENSITY, F_PRESSURE, F_MATERIAL, F_COLOR, \
     F_IS_DYNAMIC, F_GRID_IDS, F_GRID_PARTICLES_NUM, F_PID, F_RIGID_REST_CM = range(16)
 # enum SphOption
-OPT_GATHER_IMPL, OPT_TIMING, OPT_FUSED_STEP, OPT_BRICK_SHAPE = range(4)
+OPT_GATHER_IMPL, OPT_TIMING, OPT_FUSED_STEP, OPT_BRICK_SHAPE, OPT_NO_DYNAMIC_SOLIDS = range(5)
 
 ABI_VERSION = 1
 
@@ -73,6 +73,13 @@ SYMBOLS = [
     ("sph_sync", C.c_int32, [_ctx]),
     ("sph_get_timings", C.c_int32, [_ctx, C.POINTER(SphTimings)]),
     ("sph_reset_timings", C.c_int32, [_ctx]),
+    ("sph_get_particle_count", C.c_int32, [_ctx, C.POINTER(C.c_int32)]),
+    ("sph_layer_offsets", C.c_int32, [_ctx, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]),
+    ("sph_select_range", C.c_int32, [_ctx, C.c_int32, C.c_int32]),
+    ("sph_pack_range", C.c_int32, [_ctx, C.c_int32, C.c_int32, C.c_void_p]),
+    ("sph_append_records", C.c_int32, [_ctx, C.c_void_p, C.c_int32]),
+    ("sph_sort", C.c_int32, [_ctx]),
+    ("sph_sweeps", C.c_int32, [_ctx]),
 ]
 
 _LIB = None
@@ -84,6 +91,26 @@ class SphError(RuntimeError):
 
 def library_path() -> str:
     return _build.LIB
+
+
+def _preload_shared_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME
+    as /opt/rocm's); whichever copy is mapped first serves both torch and libsph_hip.so, and torch
+    cannot initialise on the system copy.  So when torch is installed, map its copy first -- then the
+    import order of torch and this package no longer matters.  Without torch the system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def load(build_if_missing: bool = True):
@@ -100,6 +127,7 @@ def load(build_if_missing: bool = True):
                 raise SphError(f"libsph_hip.so is missing and could not be built: {e}") from e
     if not os.path.exists(path):
         raise SphError(f"{path} not found: run `python -m sph_taichi_amd.build` (needs hipcc)")
+    _preload_shared_hip_runtime()
     lib = C.CDLL(path)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch

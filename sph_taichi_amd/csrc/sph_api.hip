@@ -36,8 +36,9 @@ DevView sph_view(const SphContext* c) {
         else if (q <= 1.0f) d.w_d = p.k_w * 2.0f * (1.0f - q) * (1.0f - q) * (1.0f - q);
         else d.w_d = 0.0f;
     }
-    d.xm = c->xm[c->cur]; d.vf = c->vf[c->cur]; d.aux = c->aux[c->cur]; d.key = c->key[c->cur];
-    d.eos = c->eos; d.acc = c->acc; d.cell_end = c->cell_end;
+    const int o = c->in_off;
+    d.xm = c->xm[c->cur] + o; d.vf = c->vf[c->cur] + o; d.aux = c->aux[c->cur] + o; d.key = c->key[c->cur] + o;
+    d.eos = c->eos; d.acc = c->acc + o; d.cell_end = c->cell_end;
     d.x0_cold = c->x0_cold; d.rigid_rest_cm = c->rigid_rest_cm;
     return d;
 }
@@ -119,8 +120,11 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     rc = rc ? rc : alloc_dev(c, (void**)&c->scan_sums, (size_t)(c->scan_blocks + 1) * 4);
     rc = rc ? rc : alloc_dev(c, (void**)&c->glist, cap * 2 * SPH_GLIST_ROWS);
     rc = rc ? rc : alloc_dev(c, (void**)&c->gcnt, cap);
-    rc = rc ? rc : alloc_dev(c, (void**)&c->x0_cold, cap * 12);
-    rc = rc ? rc : alloc_dev(c, (void**)&c->color_cold, cap * 12);
+    const size_t cold = params->cold_capacity > 0 ? (size_t)params->cold_capacity : cap;
+    if (cold < cap) { sph_destroy(c); return sph_fail(nullptr, SPH_E_INVALID, "sph_create: cold_capacity < capacity"); }
+    c->cold_cap = (int)cold;
+    rc = rc ? rc : alloc_dev(c, (void**)&c->x0_cold, cold * 12);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->color_cold, cold * 12);
     rc = rc ? rc : alloc_dev(c, (void**)&c->rigid_rest_cm, (size_t)(params->n_objects > 0 ? params->n_objects : 1) * 12);
     rc = rc ? rc : alloc_dev(c, (void**)&c->dyn_list, cap * 4);
     rc = rc ? rc : alloc_dev(c, (void**)&c->dyn_count, 16);
@@ -165,6 +169,7 @@ int32_t sph_set_option(SphContext* c, int32_t option, int32_t value) {
         case SPH_OPT_TIMING: c->opt_timing = value ? 1 : 0; return 0;
         case SPH_OPT_FUSED_STEP: c->opt_fused = value ? 1 : 0; return 0;
         case SPH_OPT_BRICK_SHAPE: if (value < 0 || value > 3) return sph_fail(c, SPH_E_INVALID, "brick shape must be 0..3"); c->opt_brick_shape = value; return 0;
+        case SPH_OPT_NO_DYNAMIC_SOLIDS: c->opt_no_dynamic = value ? 1 : 0; c->n_dyn_host = -1; return 0;
     }
     return sph_fail(c, SPH_E_INVALID, "unknown option");
 }
@@ -176,13 +181,14 @@ int32_t sph_get_option(const SphContext* c, int32_t option, int32_t* value) {
         case SPH_OPT_TIMING: *value = c->opt_timing; return 0;
         case SPH_OPT_FUSED_STEP: *value = c->opt_fused; return 0;
         case SPH_OPT_BRICK_SHAPE: *value = c->opt_brick_shape; return 0;
+        case SPH_OPT_NO_DYNAMIC_SOLIDS: *value = c->opt_no_dynamic; return 0;
     }
     return SPH_E_INVALID;
 }
 
 int32_t sph_set_params(SphContext* c, const SphParams* p) {
     if (!c || !p) return SPH_E_INVALID;
-    if (p->capacity != c->p.capacity || p->n_objects != c->p.n_objects ||
+    if (p->capacity != c->p.capacity || p->n_objects != c->p.n_objects || p->cold_capacity != c->p.cold_capacity ||
         memcmp(p->grid_num, c->p.grid_num, sizeof(p->grid_num)) != 0 ||
         memcmp(p->cell_origin, c->p.cell_origin, sizeof(p->cell_origin)) != 0)
         return sph_fail(c, SPH_E_INVALID, "sph_set_params: sizes differ from sph_create");
@@ -217,8 +223,7 @@ static size_t field_bytes(const SphContext* c, int field) {
 
 int32_t sph_upload(SphContext* c, int32_t field, const void* host, size_t bytes) {
     if (!c || !host) return SPH_E_INVALID;
-    if (field < 0 || field >= SPH_F_COUNT_ || field == SPH_F_GRID_IDS || field == SPH_F_GRID_PARTICLES_NUM ||
-        field == SPH_F_PID)
+    if (field < 0 || field >= SPH_F_COUNT_ || field == SPH_F_GRID_IDS || field == SPH_F_GRID_PARTICLES_NUM)
         return sph_fail(c, SPH_E_INVALID, "sph_upload: field is not uploadable");
     if (bytes != field_bytes(c, field)) return sph_fail(c, SPH_E_INVALID, "sph_upload: size mismatch");
     SPH_HIP(c, hipSetDevice(c->device));
@@ -258,6 +263,7 @@ int32_t sph_download(SphContext* c, int32_t field, void* host, size_t bytes) {
 // number (and current-order list) of dynamic rigid particles; refreshed lazily
 static int refresh_dyn(SphContext* c) {
     if (c->n_dyn_host >= 0) return 0;
+    if (c->opt_no_dynamic) { c->n_dyn_host = 0; return 0; }  // the host vouches: no dynamic solids anywhere
     int rc = sphk_build_dyn_list(c);
     if (rc) return rc;
     int n = 0;
@@ -295,6 +301,7 @@ static int counting_sort(SphContext* c, bool sort_acc) {
     if (rc) return rc;
     rc = sphk_sort_scatter(c, sort_acc);
     if (rc) return rc;
+    c->in_off = 0;         // the scatter writes the other set from record 0
     c->have_keys = false;  // the histogram offsets are consumed
     c->sorted = true;
     return 0;
@@ -413,6 +420,55 @@ static int harvest_events(SphContext* c) {
     return 0;
 }
 
+// sweeps of one step after the sort; ev (nullable) = the step's 5 events, ev[1] already recorded
+static int step_sweeps(SphContext* c, hipEvent_t* ev, const int32_t* dynamic_ids, int32_t n_dynamic) {
+    int rc = 0;
+    // compute_moving_boundary_volume()                     sph_base.py:265
+    if (c->n_dyn_host > 0) { rc = sphk_gather(c, GM_BVOL_DYNAMIC); if (rc) return rc; }
+    if (c->opt_fused) {
+        rc = sphk_gather(c, GM_DENSITY_EOS);                // WCSPH.py:153 (+ EOS of :74-76)
+        if (rc) return rc;
+        if (ev) SPH_HIP(c, hipEventRecord(ev[2], c->stream));
+        rc = sphk_gather(c, GM_FORCE_FUSED);                // WCSPH.py:154-155
+        if (rc) return rc;
+    } else {
+        rc = sphk_gather(c, GM_DENSITY);
+        if (rc) return rc;
+        if (ev) SPH_HIP(c, hipEventRecord(ev[2], c->stream));
+        rc = sphk_gather(c, GM_NONPRESSURE);
+        rc = rc ? rc : sphk_eos(c);
+        rc = rc ? rc : sphk_gather(c, GM_PRESSURE);
+        if (rc) return rc;
+    }
+    if (ev) SPH_HIP(c, hipEventRecord(ev[3], c->stream));
+    // advect (WCSPH.py:156) + enforce_boundary_3D(fluid) (sph_base.py:270-271) in one pass
+    rc = sphk_advect(c, true);
+    if (rc) return rc;
+    // solve_rigid_body()                                   sph_base.py:247-260
+    if (c->n_dyn_host > 0)
+        for (int k = 0; k < n_dynamic; ++k) {
+            rc = sphk_rigid_solve(c, dynamic_ids[k]);
+            rc = rc ? rc : sphk_enforce_boundary(c, SPH_MATERIAL_SOLID);
+            if (rc) return rc;
+        }
+    return 0;
+}
+
+int32_t sph_sort(SphContext* c) {
+    ENTER(c);
+    int rc = sph_update_grid_id(c);
+    rc = rc ? rc : sph_prefix_sum(c);
+    return rc ? rc : counting_sort(c, false);
+}
+
+int32_t sph_sweeps(SphContext* c) {
+    ENTER(c);
+    int rc = need_sorted(c, "sph_sweeps");
+    rc = rc ? rc : refresh_dyn(c);
+    if (rc) return rc;
+    return step_sweeps(c, nullptr, nullptr, 0);
+}
+
 int32_t sph_step(SphContext* c, int32_t n_steps, const int32_t* dynamic_ids, int32_t n_dynamic) {
     ENTER(c);
     if (n_steps < 0 || n_dynamic < 0 || (n_dynamic > 0 && !dynamic_ids)) return sph_fail(c, SPH_E_INVALID, "sph_step: bad arguments");
@@ -432,36 +488,70 @@ int32_t sph_step(SphContext* c, int32_t n_steps, const int32_t* dynamic_ids, int
         rc = rc ? rc : counting_sort(c, false);  // acceleration is dead here: every particle's a is rewritten below
         if (rc) return rc;
         if (timing) SPH_HIP(c, hipEventRecord(ev[1], c->stream));
-        // compute_moving_boundary_volume()                     sph_base.py:265
-        if (c->n_dyn_host > 0) { rc = sphk_gather(c, GM_BVOL_DYNAMIC); if (rc) return rc; }
-        if (c->opt_fused) {
-            rc = sphk_gather(c, GM_DENSITY_EOS);                // WCSPH.py:153 (+ EOS of :74-76)
-            if (rc) return rc;
-            if (timing) SPH_HIP(c, hipEventRecord(ev[2], c->stream));
-            rc = sphk_gather(c, GM_FORCE_FUSED);                // WCSPH.py:154-155
-            if (rc) return rc;
-        } else {
-            rc = sphk_gather(c, GM_DENSITY);
-            if (rc) return rc;
-            if (timing) SPH_HIP(c, hipEventRecord(ev[2], c->stream));
-            rc = sphk_gather(c, GM_NONPRESSURE);
-            rc = rc ? rc : sphk_eos(c);
-            rc = rc ? rc : sphk_gather(c, GM_PRESSURE);
-            if (rc) return rc;
-        }
-        if (timing) SPH_HIP(c, hipEventRecord(ev[3], c->stream));
-        // advect (WCSPH.py:156) + enforce_boundary_3D(fluid) (sph_base.py:270-271) in one pass
-        rc = sphk_advect(c, true);
+        rc = step_sweeps(c, ev, dynamic_ids, n_dynamic);
         if (rc) return rc;
-        // solve_rigid_body()                                   sph_base.py:247-260
-        if (c->n_dyn_host > 0)
-            for (int k = 0; k < n_dynamic; ++k) {
-                rc = sphk_rigid_solve(c, dynamic_ids[k]);
-                rc = rc ? rc : sphk_enforce_boundary(c, SPH_MATERIAL_SOLID);
-                if (rc) return rc;
-            }
         if (timing) { SPH_HIP(c, hipEventRecord(ev[4], c->stream)); c->ev_used++; }
     }
+    return 0;
+}
+
+// ---- multi-GPU slab support ---------------------------------------------------
+int32_t sph_get_particle_count(SphContext* c, int32_t* n) {
+    if (!c || !n) return SPH_E_INVALID;
+    *n = c->N;
+    return 0;
+}
+
+int32_t sph_layer_offsets(SphContext* c, const int32_t* layers, int32_t n, int32_t* out) {
+    ENTER(c);
+    if (!layers || !out || n < 0) return SPH_E_INVALID;
+    if (!c->have_prefix) return sph_fail(c, SPH_E_STATE, "sph_layer_offsets needs the prefix sum");
+    const int per_layer = c->p.grid_num[1] * c->p.grid_num[2];
+    for (int k = 0; k < n; ++k) {
+        const int L = layers[k];
+        if (L < 0 || L > c->p.grid_num[0]) return sph_fail(c, SPH_E_INVALID, "layer out of range");
+        if (L == 0) out[k] = 0;
+        else SPH_HIP(c, hipMemcpyAsync(&out[k], c->cell_end + (size_t)L * per_layer - 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    }
+    SPH_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int32_t sph_select_range(SphContext* c, int32_t first, int32_t count) {
+    ENTER(c);
+    if (first < 0 || count < 0 || first + count > c->in_off + c->N) return sph_fail(c, SPH_E_INVALID, "sph_select_range: out of range");
+    c->in_off += first;
+    c->N = count;
+    c->have_keys = c->have_prefix = c->sorted = false;
+    c->n_dyn_host = -1;
+    return 0;
+}
+
+int32_t sph_pack_range(SphContext* c, int32_t first, int32_t count, void* dst) {
+    ENTER(c);
+    if (first < 0 || count < 0 || first + count > c->N || (count > 0 && !dst)) return sph_fail(c, SPH_E_INVALID, "sph_pack_range: out of range");
+    if (count == 0) return 0;
+    const size_t b = (size_t)count * 16, o = (size_t)c->in_off + first;
+    char* d = (char*)dst;
+    SPH_HIP(c, hipMemcpyAsync(d, c->xm[c->cur] + o, b, hipMemcpyDeviceToDevice, c->stream));
+    SPH_HIP(c, hipMemcpyAsync(d + b, c->vf[c->cur] + o, b, hipMemcpyDeviceToDevice, c->stream));
+    SPH_HIP(c, hipMemcpyAsync(d + 2 * b, c->aux[c->cur] + o, b, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+int32_t sph_append_records(SphContext* c, const void* src, int32_t count) {
+    ENTER(c);
+    if (count < 0 || (count > 0 && !src)) return SPH_E_INVALID;
+    if (c->in_off + c->N + count > c->cap) return sph_fail(c, SPH_E_NOMEM, "sph_append_records: capacity exceeded");
+    if (count == 0) return 0;
+    const size_t b = (size_t)count * 16, o = (size_t)c->in_off + c->N;
+    const char* s = (const char*)src;
+    SPH_HIP(c, hipMemcpyAsync(c->xm[c->cur] + o, s, b, hipMemcpyDeviceToDevice, c->stream));
+    SPH_HIP(c, hipMemcpyAsync(c->vf[c->cur] + o, s + b, b, hipMemcpyDeviceToDevice, c->stream));
+    SPH_HIP(c, hipMemcpyAsync(c->aux[c->cur] + o, s + 2 * b, b, hipMemcpyDeviceToDevice, c->stream));
+    c->N += count;
+    c->have_keys = c->have_prefix = c->sorted = false;
+    c->n_dyn_host = -1;
     return 0;
 }
 

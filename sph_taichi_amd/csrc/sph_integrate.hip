@@ -323,6 +323,7 @@ __global__ __launch_bounds__(TPB) void k_insert(DevView d, int field, float* __r
         case SPH_F_MATERIAL: fl = (fl & ~0xFF) | (n[i] & 0xFF); vf[3] = __int_as_float(fl); break;
         case SPH_F_COLOR: for (int k = 0; k < 3; ++k) color_cold[3 * pid + k] = n[3 * i + k]; break;
         case SPH_F_IS_DYNAMIC: fl = (fl & ~0x100) | (n[i] ? 0x100 : 0); vf[3] = __int_as_float(fl); break;
+        case SPH_F_PID: aux[3] = __int_as_float(n[i]); break;
         default: break;
     }
 }

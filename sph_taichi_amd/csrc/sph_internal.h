@@ -52,8 +52,10 @@ struct SphContext {
     bool own_stream;
     int N;    // current particle count
     int cap;  // capacity
+    int cold_cap;  // rows of x0_cold / color_cold
     int G;
     int cur;  // which ping-pong set is current
+    int in_off;  // first live record of the current set (non-zero only between sph_select_range and the next sort)
     float4* xm[2];
     float4* vf[2];
     float4* aux[2];
@@ -80,7 +82,7 @@ struct SphContext {
     size_t stage_bytes;
     bool have_keys, have_prefix, sorted;
     // options
-    int opt_gather_impl, opt_timing, opt_fused, opt_brick_shape;
+    int opt_gather_impl, opt_timing, opt_fused, opt_brick_shape, opt_no_dynamic;
     // timing
     hipEvent_t ev[SPH_MAX_TIMED_STEPS][5];
     int ev_used;

@@ -1,0 +1,332 @@
+"""x-slab decomposition of one WCSPH domain over several GPUs (the
+reference is single-device, so this has no counterpart there).
+
+Slabs.  The global cell grid is cut along x (the slowest flatten axis,
+particle_system.py:294) at planes chosen from the per-layer particle histogram so
+every rank owns about N/world particles.  Rank r owns global cell layers
+[X_r, X_r+1); its local grid adds HALO = 2 ghost layers on each side.
+
+One exchange per step.  After integrating, a rank sorts its owned particles; the
+sort makes every set of x-layers one contiguous index range, so
+
+    to the left  neighbour:  local layers [HALO-1, 2*HALO)   = leavers + first HALO owned layers
+    to the right neighbour:  local layers [nx-2*HALO, nx-HALO+1)
+
+are two contiguous ranges of packed 48-byte records (sph_pack_range: plain D2D
+copies, no pack kernel).  The receiver appends them and sorts again; ownership is
+implied by position (owned <=> local layer in [HALO, nx-HALO)): a leaver becomes
+the neighbour's particle and stays behind as a ghost.  With a 2-layer halo the
+first ghost layer's densities/pressures are computed locally and correctly, so no
+second message is needed inside the step; the reaction of the two-way coupling on
+a rigid particle is accumulated by its owner from its (ghost-layer-1) fluid
+neighbours, so nothing travels back either.  Over xGMI each message is ~HALO+1
+cell layers (C4: ~3 MB) to at most two neighbours: latency-, not bandwidth-bound.
+
+Transports: `TorchTransport` (torch.distributed P2P; backend "nccl" = RCCL on
+ROCm, "gloo" for the CPU tests) and `LocalTransport` (several logical ranks in one
+process on one GPU -- how the slab logic is verified against the single-domain run
+where only one GPU is available).
+
+Not yet supported in slab mode: dynamic rigid bodies (shape matching needs an
+all-reduce of 13 sums per body; sph_sweeps refuses), x_0/color of migrated
+particles.
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, scene as _scene
+from .config_builder import SimConfig
+from .particle_system import ParticleSystem
+
+HALO = 2
+RECORD_BYTES = 48
+
+
+class LocalTransport:
+    """Mailbox for P logical ranks driven in lock-step by one process."""
+
+    def __init__(self, world):
+        self.world = world
+        self.box = {}
+
+    def post(self, src, dst, buf, count):
+        self.box[(src, dst)] = (buf, count)
+
+    def take(self, src, dst):
+        return self.box.pop((src, dst), (None, 0))
+
+
+class TorchTransport:
+    """torch.distributed point-to-point exchange with the x-neighbours."""
+
+    def __init__(self, device):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.device = device
+        self.cpu_staging = dist.get_backend() == "gloo"
+
+    def exchange(self, send_left, n_left, send_right, n_right, alloc):
+        """send_* : uint8 device tensors (or None at the domain ends) holding n_* records.
+        Returns (recv_left, n, recv_right, n)."""
+        torch, dist = self.torch, self.dist
+        left = self.rank - 1 if self.rank > 0 else None
+        right = self.rank + 1 if self.rank < self.world - 1 else None
+        dev = "cpu" if self.cpu_staging else self.device
+        # 1) counts
+        cnt_out = {left: torch.tensor([n_left], dtype=torch.int64, device=dev),
+                   right: torch.tensor([n_right], dtype=torch.int64, device=dev)}
+        cnt_in = {p: torch.zeros(1, dtype=torch.int64, device=dev) for p in (left, right) if p is not None}
+        ops = []
+        for p in (left, right):
+            if p is not None:
+                ops.append(dist.P2POp(dist.isend, cnt_out[p], p))
+                ops.append(dist.P2POp(dist.irecv, cnt_in[p], p))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        n_in = {p: int(cnt_in[p].item()) for p in cnt_in}
+        # 2) payload
+        bufs = {}
+        ops = []
+        for p, sbuf, n in ((left, send_left, n_left), (right, send_right, n_right)):
+            if p is None:
+                continue
+            if n > 0:
+                t = sbuf[: n * RECORD_BYTES]
+                ops.append(dist.P2POp(dist.isend, t.cpu() if self.cpu_staging else t, p))
+            if n_in[p] > 0:
+                r = alloc(p == left, n_in[p])
+                bufs[p] = r
+                rt = torch.empty(n_in[p] * RECORD_BYTES, dtype=torch.uint8) if self.cpu_staging else r[: n_in[p] * RECORD_BYTES]
+                bufs[(p, "stage")] = rt
+                ops.append(dist.P2POp(dist.irecv, rt, p))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            if not self.cpu_staging and torch.cuda.is_available():
+                torch.cuda.current_stream().synchronize()   # received bytes are consumed on another stream
+        if self.cpu_staging:
+            for p in (left, right):
+                if p is not None and n_in.get(p, 0) > 0:
+                    bufs[p][: n_in[p] * RECORD_BYTES].copy_(bufs[(p, "stage")])
+        return (bufs.get(left), n_in.get(left, 0), bufs.get(right), n_in.get(right, 0))
+
+
+class SlabSolver:
+    """One rank of the slab-decomposed WCSPH solver."""
+
+    def __init__(self, scene_dict, rank, world, device=0, cuts=None, capacity_factor=1.5, use_torch_stream=False,
+                 gather_impl=1, brick_shape=0):
+        import torch
+        self.torch = torch
+        self.rank, self.world = rank, world
+        cfg = SimConfig(config=copy.deepcopy(scene_dict))
+        if cfg.get_rigid_bodies():
+            raise NotImplementedError("slab mode: RigidBodies are not supported yet")
+        geom = _scene.Geometry(cfg)
+        self.nx_global = int(geom.grid_num[0])
+        if cuts is None:
+            cuts = _scene.slab_cuts(_scene.x_layer_histogram(cfg), world, min_width=HALO + 1)
+        self.cuts = list(cuts)
+        self.x_lo, self.x_hi = self.cuts[rank], self.cuts[rank + 1]
+        if self.x_hi - self.x_lo < HALO + 1:
+            raise ValueError(f"slab {rank} is {self.x_hi - self.x_lo} layers wide; need >= {HALO + 1}")
+        hist = _scene.x_layer_histogram(cfg)
+        own = int(hist[self.x_lo:self.x_hi].sum())
+        per_layer = int(hist.max())
+        capacity = int(capacity_factor * own) + (2 * HALO + 2) * 2 * per_layer + 1024
+        self.device = device
+        self.tdev = torch.device("cuda", device)
+        stream = torch.cuda.current_stream(self.tdev).cuda_stream if use_torch_stream else None
+        self.ps = ParticleSystem(cfg, device=device, stream=stream,
+                                 slab=dict(x_lo=self.x_lo, x_hi=self.x_hi, halo=HALO, capacity=capacity))
+        self.ps.set_option(_lib.OPT_GATHER_IMPL, gather_impl)
+        self.ps.set_option(_lib.OPT_BRICK_SHAPE, brick_shape)
+        dyn_blocks = [b for b in cfg.get_rigid_blocks() if b.get("isDynamic")]
+        self.ps.set_option(_lib.OPT_NO_DYNAMIC_SOLIDS, 0 if dyn_blocks else 1)
+        self.solver = self.ps.build_solver()
+        self.nx_local = self.x_hi - self.x_lo + 2 * HALO
+        self.capacity = capacity
+        nbuf = (HALO + 2) * 2 * per_layer * RECORD_BYTES + 4096
+        self.send_buf = {side: torch.empty(nbuf, dtype=torch.uint8, device=self.tdev) for side in ("L", "R")}
+        self.recv_buf = {side: torch.empty(nbuf, dtype=torch.uint8, device=self.tdev) for side in ("L", "R")}
+        self.nbuf = nbuf
+        self.owned_range = None     # (first, count) of the owned particles in the current order
+        self.has_left, self.has_right = rank > 0, rank < world - 1
+        self.stats = {"sent": 0, "received": 0}
+
+    # -- helpers ------------------------------------------------------------
+    def _offsets(self, layers):
+        arr = (C.c_int32 * len(layers))(*layers)
+        out = (C.c_int32 * len(layers))()
+        self.ps._call("sph_layer_offsets", arr, len(layers), out)
+        return list(out)
+
+    def _alloc_recv(self, from_left, n):
+        need = n * RECORD_BYTES
+        side = "L" if from_left else "R"
+        if need > self.recv_buf[side].numel():
+            self.recv_buf[side] = self.torch.empty(need, dtype=self.torch.uint8, device=self.tdev)
+        return self.recv_buf[side]
+
+    # -- the two halves of a step around the exchange -------------------------
+    def pre_exchange(self):
+        """Drop last step's ghosts, sort the owned particles, pack the two boundary ranges."""
+        ps = self.ps
+        if self.owned_range is not None:
+            ps._call("sph_select_range", self.owned_range[0], self.owned_range[1])
+        ps._call("sph_sort")
+        nx = self.nx_local
+        o = self._offsets([HALO - 1, 2 * HALO, nx - 2 * HALO, nx - HALO + 1, nx])
+        if o[0] != 0 or o[4] != o[3]:
+            raise RuntimeError(f"rank {self.rank}: a particle crossed more than one cell layer in one step")
+        nL, nR = (o[1] - o[0]) if self.has_left else 0, (o[3] - o[2]) if self.has_right else 0
+        for side, first, n in (("L", o[0], nL), ("R", o[2], nR)):
+            if n * RECORD_BYTES > self.send_buf[side].numel():
+                self.send_buf[side] = self.torch.empty(n * RECORD_BYTES, dtype=self.torch.uint8, device=self.tdev)
+            if n > 0:
+                ps._call("sph_pack_range", first, n, C.c_void_p(self.send_buf[side].data_ptr()))
+        self.stats["sent"] += nL + nR
+        return self.send_buf["L"], nL, self.send_buf["R"], nR
+
+    def post_exchange(self, recv_left, n_left, recv_right, n_right, sweeps=True):
+        """Append the neighbours' ranges (ghosts + immigrants), sort, run the step's sweeps."""
+        ps = self.ps
+        for buf, n in ((recv_left, n_left), (recv_right, n_right)):
+            if n > 0:
+                ps._call("sph_append_records", C.c_void_p(buf.data_ptr()), n)
+        self.stats["received"] += n_left + n_right
+        ps._call("sph_sort")
+        o = self._offsets([HALO, self.nx_local - HALO])
+        self.owned_range = (o[0], o[1] - o[0])
+        if sweeps:
+            ps._call("sph_sweeps")
+
+    # -- torch.distributed driver --------------------------------------------
+    def attach(self, transport):
+        self.transport = transport
+
+    def step(self, n=1, sweeps=True):
+        for _ in range(n):
+            sL, nL, sR, nR = self.pre_exchange()
+            self.ps.sync()      # the packed ranges are written on the context's stream, RCCL reads on torch's
+            rL, mL, rR, mR = self.transport.exchange(sL if self.has_left else None, nL,
+                                                     sR if self.has_right else None, nR, self._alloc_recv)
+            self.post_exchange(rL, mL, rR, mR, sweeps=sweeps)
+
+    def initialize(self):
+        """SPHBase.initialize() (sph_base.py:80-85) for a slab: neighbour structure with halos, then the
+        static boundary volumes (ghost layer 1 sees complete neighbourhoods, so owned values are exact)."""
+        self.solver._push()
+        self.step(1, sweeps=False)
+        self.ps._call("sph_compute_boundary_volume", 0)
+
+    # -- inspection (tests) ----------------------------------------------------
+    def owned(self, names=("pid", "x", "v")):
+        first, count = self.owned_range
+        return {n: getattr(self.ps, n).to_numpy()[first:first + count] for n in names}
+
+    def close(self):
+        self.ps.close()
+
+
+def run_local_slabs(solvers, n_steps, initialize=False):
+    """Drive P SlabSolvers that live in ONE process (one GPU) in lock-step."""
+    tr = LocalTransport(len(solvers))
+    if initialize:
+        for s in solvers:
+            s.solver._push()
+    for it in range(n_steps):
+        sent = [s.pre_exchange() for s in solvers]
+        for s in solvers:
+            s.ps.sync()
+        for r, s in enumerate(solvers):
+            sL, nL, sR, nR = sent[r]
+            rl = (sent[r - 1][2], sent[r - 1][3]) if r > 0 else (None, 0)          # left neighbour's right range
+            rr = (sent[r + 1][0], sent[r + 1][1]) if r + 1 < len(solvers) else (None, 0)
+            s.post_exchange(rl[0], rl[1], rr[0], rr[1], sweeps=not initialize)
+        if initialize:
+            for s in solvers:
+                s.ps._call("sph_compute_boundary_volume", 0)
+            return
+    del tr
+
+
+def gather_by_pid(solvers, name, n_global):
+    """Global array `name` indexed by persistent id, assembled from every rank's owned particles."""
+    out = None
+    for s in solvers:
+        o = s.owned(("pid", name))
+        if out is None:
+            shape = (n_global,) + o[name].shape[1:]
+            out = np.full(shape, np.nan, dtype=o[name].dtype) if o[name].dtype.kind == "f" else np.full(shape, -1, o[name].dtype)
+        out[o["pid"]] = o[name]
+    return out
+
+
+# ---------------------------------------------------------------------------
+# bench.py --gpus N  (weak scaling: every rank owns one ~1.74 M-particle slab)
+# ---------------------------------------------------------------------------
+def slab_bench_scene(world):
+    """BASELINE.md C4 family: (64*world) x 165 x 165 particles in a (2*world, 4, 3.4) tank;
+    world = 8 is C4 itself (512 x 165 x 165 = 13,939,200 particles, 400 x 100 x 85 cells)."""
+    cfg = {
+        "domainStart": [0.0, 0.0, 0.0], "domainEnd": [2.0 * world, 4.0, 3.4], "particleRadius": 0.01,
+        "numberOfStepsPerRenderUpdate": 1, "density0": 1000, "simulationMethod": 0,
+        "gravitation": [0.0, -9.81, 0.0], "timeStepSize": 0.0004, "stiffness": 50000, "exponent": 7,
+        "boundaryHandlingMethod": 0, "exportFrame": False, "exportPly": False, "exportObj": False,
+    }
+    d = 0.02
+    counts = (64 * world, 165, 165)
+    corner = (0.04, 0.04, 0.04)
+    end = [c + (n - 0.5) * d for c, n in zip(corner, counts)]
+    return {"Configuration": cfg,
+            "FluidBlocks": [{"objectId": 0, "start": list(corner), "end": end, "translation": [0.0, 0.0, 0.0],
+                             "scale": [1, 1, 1], "velocity": [0.0, 0.0, 0.0], "density": 1000.0,
+                             "color": [50, 100, 200]}]}, counts[0] * counts[1] * counts[2]
+
+
+def run_slab_bench(args, rank, world, local_rank):
+    import time
+    import torch
+    import torch.distributed as dist
+    sd, n_global = slab_bench_scene(world)
+    s = SlabSolver(sd, rank, world, device=local_rank, gather_impl=args.gather_impl, brick_shape=args.brick_shape)
+    s.attach(TorchTransport(torch.device("cuda", local_rank)))
+    s.initialize()
+    s.step(args.warmup)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    s.step(args.steps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    red_dev = torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else torch.device("cpu")
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = float(dt.item())
+    own = torch.tensor([s.owned_range[1]], dtype=torch.int64, device=red_dev)
+    dist.all_reduce(own)
+    from bench import REF_PARTICLES  # noqa: E402
+    steps_per_s = args.steps / dt
+    line = {
+        "metric": "WCSPH steps/sec at 1.74 M particles (+ ms/step breakdown sort/neighbour/force)",
+        "value": round(steps_per_s * n_global / REF_PARTICLES, 3), "unit": "steps/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"c4_family_dambreak_{64 * world}x165x165", "particles": n_global,
+                   "particles_owned_sum": int(own.item()), "cuts": s.cuts, "halo_layers": HALO,
+                   "sent_records_per_step": round(s.stats["sent"] / max(args.steps + args.warmup + 1, 1), 1),
+                   "backend": dist.get_backend(),
+                   "parallelism": f"x-slab x{world}, 1 exchange/step over RCCL P2P"},
+        "steps_per_s_job": round(steps_per_s, 3),
+        "roofline": None, "cpu_baseline": None,
+    }
+    s.close()
+    return line

@@ -20,10 +20,19 @@ from .field import DeviceField, HostScalar
 
 class ParticleSystem:
     def __init__(self, config: SimConfig, GGUI=False, device: int = 0, stream=None, scene_dir: str | None = None,
-                 verbose: bool = False):
+                 verbose: bool = False, slab: dict | None = None):
+        """`slab` (multi-GPU, no reference counterpart) = dict(x_lo, x_hi, halo, capacity): this
+        context owns the global cell layers [x_lo, x_hi) plus `halo` ghost layers on each side."""
         self.cfg = config
         self.GGUI = GGUI
-        sc = _scene.build_scene(config, base_dir=scene_dir, verbose=verbose)
+        self.slab = slab
+        x_filter = None
+        if slab is not None:
+            g0 = _scene.Geometry(config)
+            nx = int(g0.grid_num[0])
+            x_filter = lambda xs: ((_scene.x_layer_of(xs, g0.grid_size, nx) >= slab["x_lo"])
+                                   & (_scene.x_layer_of(xs, g0.grid_size, nx) < slab["x_hi"]))
+        sc = _scene.build_scene(config, base_dir=scene_dir, verbose=verbose, x_filter=x_filter)
         g = sc.geom
         self._scene = sc
         # ---- scalars, same names as the reference (particle_system.py:17-46) ----
@@ -62,7 +71,7 @@ class ParticleSystem:
             msg = self._lib.sph_last_error(None)
             raise _lib.SphError(f"sph_create failed (rc={rc}): {msg.decode() if msg else ''}")
         self._ctx = ctx
-        n = lambda: self.particle_max_num
+        n = self.count if slab is not None else (lambda: self.particle_max_num)
         F = _lib
         mk = lambda fid, dt, vec=0, w=True, name="": DeviceField(self, fid, dt, n, vec, w, name)
         self.object_id = mk(F.F_OBJECT_ID, np.int32, name="object_id")
@@ -78,8 +87,8 @@ class ParticleSystem:
         self.color = mk(F.F_COLOR, np.int32, 3, name="color")
         self.is_dynamic = mk(F.F_IS_DYNAMIC, np.int32, name="is_dynamic")
         self.grid_ids = mk(F.F_GRID_IDS, np.int32, w=False, name="grid_ids")
-        self.pid = mk(F.F_PID, np.int32, w=False, name="pid")
-        G = int(np.prod(self.grid_num))
+        self.pid = mk(F.F_PID, np.int32, name="pid")
+        G = int(np.prod(self._local_grid_num))
         self.grid_particles_num = DeviceField(self, F.F_GRID_PARTICLES_NUM, np.int32, lambda: G, 0, False,
                                               "grid_particles_num")
         if self.num_rigid_bodies > 0:
@@ -92,6 +101,8 @@ class ParticleSystem:
 
         # ---- upload the initial particles (the reference's _add_particles, :260-284) ----
         for name, arr in sc.arrays.items():
+            if name == "pid" and slab is None:
+                continue            # default pid = index at creation
             getattr(self, name).from_numpy(arr)
         self.particle_num[None] = self.particle_max_num
 
@@ -100,10 +111,21 @@ class ParticleSystem:
         g = sc.geom
         cfg = self.cfg
         p = _lib.SphParams()
-        p.n_particles = sc.particle_max_num
-        p.capacity = max(sc.particle_max_num, 1)
-        p.grid_num = (C.c_int32 * 3)(*[int(v) for v in g.grid_num])
-        p.cell_origin = (C.c_int32 * 3)(0, 0, 0)
+        if self.slab is None:
+            p.n_particles = sc.particle_max_num
+            p.capacity = max(sc.particle_max_num, 1)
+            local_grid = [int(v) for v in g.grid_num]
+            p.cell_origin = (C.c_int32 * 3)(0, 0, 0)
+            p.cold_capacity = 0
+        else:
+            sl = self.slab
+            p.n_particles = int(sc.arrays["x"].shape[0])
+            p.capacity = max(int(sl["capacity"]), p.n_particles, 1)
+            local_grid = [sl["x_hi"] - sl["x_lo"] + 2 * sl["halo"], int(g.grid_num[1]), int(g.grid_num[2])]
+            p.cell_origin = (C.c_int32 * 3)(sl["x_lo"] - sl["halo"], 0, 0)
+            p.cold_capacity = max(sc.particle_max_num, p.capacity)
+        self._local_grid_num = local_grid
+        p.grid_num = (C.c_int32 * 3)(*local_grid)
         p.n_objects = sc.n_objects
         p.grid_size = g.grid_size
         p.support_radius = g.support_radius
@@ -134,6 +156,12 @@ class ParticleSystem:
     def _call(self, name, *args):
         rc = getattr(self._lib, name)(self._ctx, *args)
         _lib.check(self._lib, self._ctx, rc, name)
+
+    def count(self) -> int:
+        """Live particle count of this context (== particle_max_num on a single GPU)."""
+        n = C.c_int32()
+        self._call("sph_get_particle_count", C.byref(n))
+        return int(n.value)
 
     def set_option(self, option: int, value: int):
         self._call("sph_set_option", int(option), int(value))

@@ -60,16 +60,32 @@ class SceneBuilder:
     """Accumulates particles object by object (the reference appends to Taichi
     fields through _add_particles; here they are NumPy chunks)."""
 
-    def __init__(self, geom: Geometry):
+    def __init__(self, geom: Geometry, x_filter=None):
         self.g = geom
         self.chunks = {k: [] for k in ARRAY_SPECS}
-        self.count = 0
+        self.chunks["pid"] = []
+        self.count = 0          # particles kept (== global_count without a filter)
+        self.global_count = 0   # particles of the whole scene so far; pid = index in the whole scene
+        self.x_filter = x_filter
 
     def add_particles(self, object_id, n, positions, velocity, density, pressure, material, is_dynamic, color):
         """particle_system.py:223-284 (add_particle semantics: x_0 = x, m_V = m_V0, m = m_V0*density)."""
         positions = np.asarray(positions, dtype=np.float32).reshape(n, 3)
+        pid = self.global_count + np.arange(n, dtype=np.int64)
+        self.global_count += n
+        if self.x_filter is not None:
+            keep = self.x_filter(positions[:, 0])
+            sel = lambda a, w=None: np.asarray(a).reshape((n, w) if w else (n,))[keep]
+            positions, pid = positions[keep], pid[keep]
+            velocity, color = sel(velocity, 3), sel(color, 3)
+            density, pressure, material, is_dynamic = sel(density), sel(pressure), sel(material), sel(is_dynamic)
+            n = positions.shape[0]
+        self._append(object_id, n, positions, velocity, density, pressure, material, is_dynamic, color, pid)
+
+    def _append(self, object_id, n, positions, velocity, density, pressure, material, is_dynamic, color, pid):
         density = np.asarray(density, dtype=np.float32).reshape(n)
         c = self.chunks
+        c["pid"].append(np.asarray(pid, dtype=np.int32))
         c["object_id"].append(np.full(n, object_id, dtype=np.int32))
         c["x"].append(positions)
         c["x_0"].append(positions.copy())
@@ -77,16 +93,37 @@ class SceneBuilder:
         c["acceleration"].append(np.zeros((n, 3), dtype=np.float32))
         c["m_V"].append(np.full(n, self.g.m_V0, dtype=np.float32))
         c["m"].append((np.float32(self.g.m_V0) * density).astype(np.float32))
+        self.count += n
         c["density"].append(density)
         c["pressure"].append(np.asarray(pressure, dtype=np.float32).reshape(n))
         c["material"].append(np.asarray(material, dtype=np.int32).reshape(n))
         c["is_dynamic"].append(np.asarray(is_dynamic, dtype=np.int32).reshape(n))
         c["color"].append(np.asarray(color, dtype=np.int32).reshape(n, 3))
-        self.count += n
 
     def add_cube(self, object_id, lower_corner, cube_size, material, is_dynamic, color=(0, 0, 0), density=None,
                  pressure=None, velocity=None):
         """particle_system.py:458-495."""
+        d = self.g.particle_diameter
+        axes = [np.arange(lower_corner[i], lower_corner[i] + cube_size[i], d) for i in range(self.g.dim)]
+        n_full = len(axes[0]) * len(axes[1]) * len(axes[2])
+        if self.x_filter is not None:
+            # subset at axis level: only the x-planes of this slab are ever materialised
+            keep_ix = np.nonzero(self.x_filter(axes[0].astype(np.float32)))[0]
+            grid = np.array(np.meshgrid(axes[0][keep_ix], axes[1], axes[2], sparse=False, indexing="ij"),
+                            dtype=np.float32)
+            pos = grid.reshape(3, -1).transpose().copy()
+            ny, nz = len(axes[1]), len(axes[2])
+            pid = (self.global_count + (keep_ix[:, None, None].astype(np.int64) * ny
+                                        + np.arange(ny)[None, :, None]) * nz + np.arange(nz)[None, None, :]).reshape(-1)
+            self.global_count += n_full
+            n = pos.shape[0]
+            vel = np.zeros_like(pos) if velocity is None else np.tile(np.asarray(velocity, dtype=np.float32), (n, 1))
+            self._append(object_id, n, pos, vel,
+                         np.full(n, density if density is not None else 1000.0, dtype=np.float32),
+                         np.full(n, pressure if pressure is not None else 0.0, dtype=np.float32),
+                         np.full(n, material, dtype=np.int32), np.full(n, is_dynamic, dtype=np.int32),
+                         np.tile(np.asarray(color, dtype=np.int32), (n, 1)), pid)
+            return n
         pos = cube_positions(lower_corner, cube_size, self.g.particle_diameter, self.g.dim)
         n = pos.shape[0]
         vel = np.zeros_like(pos) if velocity is None else np.tile(np.asarray(velocity, dtype=np.float32), (n, 1))
@@ -102,6 +139,7 @@ class SceneBuilder:
         for k, (dt, vec) in ARRAY_SPECS.items():
             shape = (0, vec) if vec else (0,)
             out[k] = np.concatenate(self.chunks[k]).astype(dt) if self.chunks[k] else np.zeros(shape, dtype=dt)
+        out["pid"] = np.concatenate(self.chunks["pid"]).astype(np.int32) if self.chunks["pid"] else np.zeros(0, np.int32)
         return out
 
 
@@ -109,7 +147,7 @@ class Scene:
     """Result of build_scene: geometry, object bookkeeping and initial arrays."""
 
 
-def build_scene(cfg, base_dir: str | None = None, verbose: bool = False) -> Scene:
+def build_scene(cfg, base_dir: str | None = None, verbose: bool = False, x_filter=None) -> Scene:
     g = Geometry(cfg)
     sc = Scene()
     sc.geom = g
@@ -149,7 +187,7 @@ def build_scene(cfg, base_dir: str | None = None, verbose: bool = False) -> Scen
     sc.n_objects = sc.num_rigid_bodies + len(fluid_blocks)     # len(rigid_rest_cm), particle_system.py:93
 
     # ---- particles (particle_system.py:148-211) ----
-    b = SceneBuilder(g)
+    b = SceneBuilder(g, x_filter)
     for fluid in fluid_blocks:
         off = np.array(fluid["translation"])
         start, end = np.array(fluid["start"]) + off, np.array(fluid["end"]) + off
@@ -171,8 +209,8 @@ def build_scene(cfg, base_dir: str | None = None, verbose: bool = False) -> Scen
                         body["density"] * np.ones(n, dtype=np.float32), np.zeros(n, dtype=np.float32),
                         np.zeros(n, dtype=np.int32), int(bool(dyn)) * np.ones(n, dtype=np.int32),
                         np.tile(np.array(body["color"], dtype=np.int32), (n, 1)))
-    if b.count != sc.particle_max_num:
-        raise ValueError(f"scene is inconsistent: blocks create {b.count} particles but start/end predict "
+    if b.global_count != sc.particle_max_num:
+        raise ValueError(f"scene is inconsistent: blocks create {b.global_count} particles but start/end predict "
                          f"{sc.particle_max_num} (the reference would overflow its fields here)")
     sc.arrays = b.arrays()
     sc.dynamic_rigid_ids = [oid for oid in sc.object_id_rigid_body if sc.object_collection[oid]["isDynamic"]]
@@ -186,3 +224,44 @@ def kernel_constants(support_radius: float, viscosity: float, dim: int = 3):
     k /= support_radius ** dim
     k_dw = 6.0 * (8 / np.pi) / support_radius ** dim
     return dict(k_w=k, k_dw=k_dw, visc_d_nu=2 * (dim + 2) * viscosity, visc_eps=0.01 * support_radius ** 2)
+
+
+def x_layer_of(xs, grid_size, nx):
+    """Cell x-layer of f32 coordinates, computed exactly like the device hash
+    (particle_system.py:287-289: f32 divide, truncate; clamped to the grid)."""
+    layer = (np.asarray(xs, dtype=np.float32) / np.float32(grid_size)).astype(np.int64)
+    return np.clip(layer, 0, nx - 1)
+
+
+def x_layer_histogram(cfg):
+    """Particles per global x cell layer, from the block axes alone (no particle arrays)."""
+    g = Geometry(cfg)
+    nx = int(g.grid_num[0])
+    hist = np.zeros(nx, dtype=np.int64)
+    for blk in list(cfg.get_fluid_blocks()) + list(cfg.get_rigid_blocks()):
+        off = np.array(blk["translation"])
+        start, end = np.array(blk["start"]) + off, np.array(blk["end"]) + off
+        size = (end - start) * np.array(blk["scale"])
+        axes = [np.arange(start[i], start[i] + size[i], g.particle_diameter) for i in range(3)]
+        np.add.at(hist, x_layer_of(axes[0], g.grid_size, nx), len(axes[1]) * len(axes[2]))
+    if cfg.get_rigid_bodies():
+        raise NotImplementedError("x_layer_histogram: RigidBodies need the voxelised points; build the scene instead")
+    return hist
+
+
+def slab_cuts(hist, world, min_width=3):
+    """Cell-layer cut planes X_0=0 < X_1 < ... < X_world=nx giving every rank about the same
+    number of particles.  Each slab is at least `min_width` layers wide."""
+    nx = len(hist)
+    if world * min_width > nx:
+        raise ValueError("too many ranks for this grid")
+    cum = np.concatenate([[0], np.cumsum(hist)])
+    total = cum[-1]
+    cuts = [0]
+    for r in range(1, world):
+        x = int(np.searchsorted(cum, total * r / world, side="left"))
+        x = max(x, cuts[-1] + min_width)
+        x = min(x, nx - (world - r) * min_width)
+        cuts.append(x)
+    cuts.append(nx)
+    return cuts

@@ -1,0 +1,130 @@
+"""Slab decomposition.  CPU: cut planes, scene subsetting, and the
+TorchTransport exchange over gloo with world_size 2 and 3.  GPU (one device):
+P logical slabs in one process, and 2 gloo ranks sharing the GPU, against the
+single-domain run -- same particles, same trajectories."""
+import copy
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import scenes
+from sph_taichi_amd import scene as scene_mod
+from sph_taichi_amd.config_builder import SimConfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _spawn(mode, world, out, extra=()):
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "slab_worker.py"), mode, str(r), str(world),
+                               str(port), out, *extra], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-3000:]
+
+
+def test_slab_cuts_balance_and_width():
+    hist = np.zeros(400, dtype=np.int64)
+    hist[1:257] = 165 * 165 * 2                      # C4: 512 particle planes in cells 1..256
+    cuts = scene_mod.slab_cuts(hist, 8)
+    assert cuts[0] == 0 and cuts[-1] == 400 and all(b - a >= 3 for a, b in zip(cuts, cuts[1:]))
+    own = [hist[a:b].sum() for a, b in zip(cuts, cuts[1:])]
+    assert max(own) - min(own) <= hist.max()           # balanced to one cell layer
+    with pytest.raises(ValueError):
+        scene_mod.slab_cuts(np.ones(5), 4)
+
+
+def test_scene_subsets_partition_the_scene():
+    sd = scenes.fluid_with_rigid_blocks()
+    cfg, full = scenes.build(sd)
+    hist = scene_mod.x_layer_histogram(cfg)
+    assert hist.sum() == full.particle_max_num
+    layers = scene_mod.x_layer_of(full.arrays["x"][:, 0], full.geom.grid_size, int(full.geom.grid_num[0]))
+    assert np.array_equal(np.bincount(layers, minlength=len(hist)), hist)
+    cuts = scene_mod.slab_cuts(hist, 3)
+    nx = int(full.geom.grid_num[0])
+    pids = []
+    for r in range(3):
+        lo, hi = cuts[r], cuts[r + 1]
+        f = lambda xs: (scene_mod.x_layer_of(xs, full.geom.grid_size, nx) >= lo) & (scene_mod.x_layer_of(xs, full.geom.grid_size, nx) < hi)
+        sub = scene_mod.build_scene(SimConfig(config=copy.deepcopy(sd)), x_filter=f)
+        a = sub.arrays
+        for k in ("x", "v", "density", "material", "is_dynamic", "object_id", "m"):
+            assert np.array_equal(a[k], full.arrays[k][a["pid"]]), k
+        pids.append(a["pid"])
+    assert np.array_equal(np.sort(np.concatenate(pids)), np.arange(full.particle_max_num))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_transport_gloo(world, tmp_path):
+    out = str(tmp_path / "res.txt")
+    _spawn("transport", world, out)
+    assert open(out).read() == "ok"
+
+
+# ---------------------------------------------------------------------------
+def _single_domain(sd, steps):
+    cfg, sc = scenes.build(sd)
+    ps, solver = scenes.make_ps(sd)
+    solver.initialize()
+    solver.step(steps)
+    out = {k: scenes.ps_by_pid(ps, k) for k in ("x", "v", "density")}
+    ps.close()
+    return out, sc.particle_max_num
+
+
+def _slab_scenes():
+    a = scenes.fluid_only(counts=(20, 10, 8), start=(0.1, 0.1, 0.1), velocity=(1.5, -1.0, 0.0))   # drifts across the cuts
+    b = scenes.fluid_with_rigid_blocks()
+    return [a, b]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("which", [0, 1])
+def test_local_slabs_match_single_domain(world, which):
+    from sph_taichi_amd.distributed import SlabSolver, run_local_slabs, gather_by_pid
+    sd = _slab_scenes()[which]
+    steps = 25
+    ref, n = _single_domain(sd, steps)
+    solvers = [SlabSolver(sd, r, world, device=0) for r in range(world)]
+    run_local_slabs(solvers, 1, initialize=True)
+    run_local_slabs(solvers, steps)
+    x = gather_by_pid(solvers, "x", n)
+    assert not np.isnan(x).any(), "a particle is owned by no rank"
+    owned_total = sum(s.owned_range[1] for s in solvers)
+    assert owned_total == n, "a particle is owned by two ranks"
+    assert sum(s.stats["sent"] for s in solvers) > 0
+    assert scenes.rel_l2(x, ref["x"]) <= 2e-6
+    assert scenes.rel_l2(gather_by_pid(solvers, "v", n), ref["v"]) <= 2e-4
+    for s in solvers:
+        s.close()
+
+
+@pytest.mark.gpu
+def test_two_gloo_ranks_on_one_gpu(tmp_path):
+    sd = _slab_scenes()[0]
+    steps = 20
+    ref, n = _single_domain(sd, steps)
+    scene_file = str(tmp_path / "scene.json")
+    json.dump(sd, open(scene_file, "w"))
+    out = str(tmp_path / "res.npz")
+    _spawn("slabs", 2, out, extra=(scene_file, str(steps)))
+    z = np.load(out)
+    assert np.array_equal(np.sort(z["pid"]), np.arange(n))
+    x = np.empty_like(ref["x"])
+    x[z["pid"]] = z["x"]
+    assert scenes.rel_l2(x, ref["x"]) <= 2e-6

@@ -80,7 +80,7 @@ def test_library_exports_every_header_symbol():
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.sph_abi_version() == 1
-    assert ctypes.sizeof(_lib.SphParams) == 4 * (2 + 3 + 3 + 1 + 10 + 3 + 3 + 1 + 3 + 4)
+    assert ctypes.sizeof(_lib.SphParams) == 4 * (2 + 3 + 3 + 2 + 10 + 3 + 3 + 1 + 3 + 4)
 
 
 def test_product_fails_loudly_without_gpu():

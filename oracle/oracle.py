@@ -39,7 +39,7 @@ class _State(C.Structure):
         ("exponent", C.c_float), ("viscosity", C.c_float), ("surface_tension", C.c_float),
         ("dt", C.c_float), ("g", _F3), ("domain_size", _F3), ("padding", C.c_float), ("wall_hi", _F3),
         ("k_w", C.c_float), ("k_dw", C.c_float), ("visc_d_nu", C.c_float), ("visc_eps", C.c_float),
-        ("omp_threads", C.c_int32), ("pad_", C.c_int32),
+        ("omp_threads", C.c_int32), ("rigid_sums_f64", C.c_int32),
         ("object_id", _pi), ("x", _pf), ("x_0", _pf), ("v", _pf), ("acceleration", _pf),
         ("m_V", _pf), ("m", _pf), ("density", _pf), ("pressure", _pf),
         ("material", _pi), ("color", _pi), ("is_dynamic", _pi),
@@ -113,7 +113,7 @@ class Oracle:
     """
 
     def __init__(self, params: dict, arrays: dict, n_objects: int = 1,
-                 rigid_body_ids=(), dynamic_ids=(), omp_threads: int = 1):
+                 rigid_body_ids=(), dynamic_ids=(), omp_threads: int = 1, rigid_sums_f64: bool = False):
         L = lib()
         self.L = L
         N = int(np.asarray(arrays["x"]).shape[0])
@@ -148,6 +148,7 @@ class Oracle:
         kc = kernel_constants(h, s.viscosity)
         s.k_w, s.k_dw, s.visc_d_nu, s.visc_eps = kc["k_w"], kc["k_dw"], kc["visc_d_nu"], kc["visc_eps"]
         s.omp_threads = int(omp_threads)
+        s.rigid_sums_f64 = int(bool(rigid_sums_f64))
         self.a = {}
 
         def alloc(name, dtype, vec):

@@ -62,7 +62,7 @@ typedef struct OracleState {
     float visc_d_nu;         /* 2*(dim+2)*viscosity   WCSPH.py:104,112 */
     float visc_eps;          /* 0.01*h^2              WCSPH.py:113 */
     int32_t omp_threads;     /* 1 = deterministic serial order */
-    int32_t pad_;
+    int32_t rigid_sums_f64;  /* test switch (not in the reference): accumulate the shape-matching sums in f64 */
     /* per-particle state   particle_system.py:101-113 */
     int32_t *object_id; float *x; float *x_0; float *v; float *acceleration;
     float *m_V; float *m; float *density; float *pressure;
@@ -434,6 +434,17 @@ void oracle_enforce_boundary_3D(OracleState *s, int32_t particle_type) {
 
 /* sph_base.py:182-192  compute_com */
 static void compute_com(const OracleState *s, int32_t object_id, float cm[3]) {
+    if (s->rigid_sums_f64) { /* same formula, f64 accumulators: isolates the f32 summation noise of the reference */
+        double sm = 0.0, c[3] = {0.0, 0.0, 0.0};
+        for (int32_t p = 0; p < s->N; ++p)
+            if (is_dynamic_rigid_body(s, p) && s->object_id[p] == object_id) {
+                const float mass = s->m_V0 * s->density[p];
+                for (int d = 0; d < 3; ++d) c[d] += (double)(mass * s->x[3 * p + d]);
+                sm += mass;
+            }
+        for (int d = 0; d < 3; ++d) cm[d] = (float)c[d] / (float)sm;
+        return;
+    }
     float sum_m = 0.0f;
     cm[0] = cm[1] = cm[2] = 0.0f;
     for (int32_t p = 0; p < s->N; ++p) {
@@ -537,15 +548,20 @@ void oracle_solve_constraints(OracleState *s, int32_t object_id, float R_out[9])
     float cm[3];
     compute_com(s, object_id, cm);
     float A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double Ad[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const float *rc = &s->rigid_rest_cm[3 * object_id];
     for (int32_t p = 0; p < s->N; ++p) {
         if (is_dynamic_rigid_body(s, p) && s->object_id[p] == object_id) {
             const float q[3] = {s->x_0[3 * p] - rc[0], s->x_0[3 * p + 1] - rc[1], s->x_0[3 * p + 2] - rc[2]};
             const float pp[3] = {s->x[3 * p] - cm[0], s->x[3 * p + 1] - cm[1], s->x[3 * p + 2] - cm[2]};
             const float w = s->m_V0 * s->density[p];
-            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A[3 * i + j] += w * (pp[i] * q[j]);
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+                A[3 * i + j] += w * (pp[i] * q[j]);
+                Ad[3 * i + j] += (double)(w * (pp[i] * q[j]));
+            }
         }
     }
+    if (s->rigid_sums_f64) for (int i = 0; i < 9; ++i) A[i] = (float)Ad[i];
     float R[9];
     polar_rotation(A, R);
     int all_small = 1;

@@ -116,19 +116,31 @@ def voxelize_filled_points(mesh: TriMesh, pitch: float) -> np.ndarray:
 
 def load_rigid_body(rigid_body: dict, particle_diameter: float, base_dir: str = "."):
     """particle_system.py:421-447.  Returns (voxel points f64 [n,3], mesh backup)."""
-    path = rigid_body["geometryFile"]
-    if not os.path.isabs(path) and not os.path.exists(path):
+    d = particle_diameter
+    pts_file = rigid_body.get("voxelizedPointsFile")
+    if pts_file and not os.path.isabs(pts_file) and not os.path.exists(pts_file):
+        pts_file = os.path.join(base_dir, pts_file)
+    path = rigid_body.get("geometryFile")
+    if path and not os.path.isabs(path) and not os.path.exists(path):
         path = os.path.join(base_dir, path)
-    mesh = load_mesh(path)
-    mesh.apply_scale(rigid_body["scale"])
     offset = np.array(rigid_body["translation"], dtype=np.float64)
-    angle = rigid_body["rotationAngle"] / 360 * 2 * 3.1415926   # particle_system.py:427
-    direction = rigid_body["rotationAxis"]
-    mesh.apply_transform(rotation_matrix(angle, direction, mesh.vertices.mean(axis=0)))
-    mesh.vertices = mesh.vertices + offset
-    backup = mesh.copy()
-    if rigid_body.get("voxelizedPointsFile"):
-        pts = np.load(rigid_body["voxelizedPointsFile"]).astype(np.float64)
+    mesh = backup = None
+    if path and os.path.exists(path):
+        mesh = load_mesh(path)
+        mesh.apply_scale(rigid_body["scale"])
+        angle = rigid_body["rotationAngle"] / 360 * 2 * 3.1415926   # particle_system.py:427
+        direction = rigid_body["rotationAxis"]
+        mesh.apply_transform(rotation_matrix(angle, direction, mesh.vertices.mean(axis=0)))
+        mesh.vertices = mesh.vertices + offset
+        backup = mesh.copy()
+    elif not pts_file:
+        raise FileNotFoundError(f"rigid body geometry {path!r} not found and no voxelizedPointsFile given")
+    if pts_file:
+        # pre-voxelised point set (scale/rotation already applied, translation not): exchanges the
+        # trimesh-dependent voxel set as a fixture (SURVEY App. D)
+        pts = np.load(pts_file).astype(np.float64) + offset
     else:
-        pts = voxelize_filled_points(mesh, particle_diameter)
+        pts = voxelize_filled_points(mesh, d)
+    if backup is None:
+        backup = TriMesh(pts.copy(), np.zeros((0, 3), dtype=np.int64))   # no mesh: export the particle cloud
     return pts, backup

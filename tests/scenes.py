@@ -77,13 +77,13 @@ def solver_params(cfg, scene):
                 dt=cfg.get_cfg("timeStepSize"), g=cfg.get_cfg("gravitation"))
 
 
-def make_oracle(cfg, scene, omp_threads=1):
+def make_oracle(cfg, scene, omp_threads=1, rigid_sums_f64=False):
     from oracle.oracle import Oracle
     # RigidBlocks are not in object_id_rigid_body in the reference (particle_system.py:171-188):
     # only RigidBodies are shape-matched.  Tests that want a shape-matched block pass ids explicitly.
     return Oracle(solver_params(cfg, scene), scene.arrays, n_objects=max(scene.n_objects, 1),
                   rigid_body_ids=sorted(scene.object_id_rigid_body), dynamic_ids=sorted(scene.dynamic_rigid_ids),
-                  omp_threads=omp_threads)
+                  omp_threads=omp_threads, rigid_sums_f64=rigid_sums_f64)
 
 
 def rel_l2(a, b):

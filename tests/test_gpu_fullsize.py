@@ -1,0 +1,146 @@
+"""Full-size cases of BASELINE.md section 3 on the GPU.
+
+C2  dragon_bath.json equivalent (423,500 fluid + 18,496 static dragon voxels): HIP vs oracle.
+C3  armadillo_bath_dynamic.json equivalent (1,723,968 fluid + 3 dynamic bodies, stand-in mesh):
+    HIP vs oracle through first contact (two-way coupling + shape matching at scale).
+C3' uniform 1,747,584-particle box: size-independent properties of the sort and the sweeps.
+The oracle runs multi-threaded here (OpenMP), so only tolerance comparisons are made against it.
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+CFG = dict(scenes.BASE_CFG, domainEnd=[5.0, 3.0, 2.0])
+
+
+def dragon_bath_scene():
+    """data/scenes/dragon_bath.json with the dragon's voxel set taken from the fixture."""
+    return {
+        "Configuration": copy.deepcopy(CFG),
+        "RigidBodies": [{"objectId": 1, "voxelizedPointsFile": os.path.join(GOLDEN, "dragon_bath_body.npy"),
+                         "translation": [3.5, 0.05, 1.0], "rotationAxis": [0, 1, 0], "rotationAngle": 0,
+                         "scale": [1, 1, 1], "velocity": [0.0, 0.0, 0.0], "density": 1000.0,
+                         "color": [255, 255, 255], "isDynamic": False}],
+        "FluidBlocks": [{"objectId": 0, "start": [0.1, 0.1, 0.5], "end": [1.2, 2.9, 1.6],
+                         "translation": [0.2, 0.0, 0.2], "scale": [1, 1, 1], "velocity": [0.0, -1.0, 0.0],
+                         "density": 1000.0, "color": [50, 100, 200]}],
+    }
+
+
+def armadillo_equiv_scene(body_y=1.74):
+    """data/scenes/armadillo_bath_dynamic.json with a stand-in mesh (the armadillo blob is missing from the
+    reference checkout) and the bodies lowered to just above the fluid so contact happens within ~10 steps."""
+    bodies = []
+    for oid, x, rho, col in ((1, 4.0, 7874.0, [255, 255, 255]), (2, 2.5, 1700.0, [255, 100, 50]),
+                             (3, 1.0, 300.0, [100, 100, 50])):
+        bodies.append({"objectId": oid, "voxelizedPointsFile": os.path.join(GOLDEN, "armadillo_standin.npy"),
+                       "translation": [x, body_y, 1.2], "rotationAxis": [0, 1, 0], "rotationAngle": 180,
+                       "scale": [0.25, 0.25, 0.25], "velocity": [0.0, -5.0, 0.0], "density": rho, "color": col,
+                       "isDynamic": True})
+    return {
+        "Configuration": copy.deepcopy(CFG),
+        "RigidBodies": bodies,
+        "FluidBlocks": [{"objectId": 0, "start": [0.04, 0.04, 0.04], "end": [4.96, 1.50, 1.96],
+                         "translation": [0.0, 0.0, 0.0], "scale": [1, 1, 1], "velocity": [0.0, 0.0, 0.0],
+                         "density": 1000.0, "color": [50, 100, 200]}],
+    }
+
+
+def _threads():
+    from oracle.oracle import max_threads
+    return max_threads()
+
+
+def test_c2_dragon_bath_equivalent():
+    sd = dragon_bath_scene()
+    cfg, sc = scenes.build(sd)
+    assert sc.fluid_particle_num == 55 * 140 * 55 and sc.solid_particle_num == 18496
+    o = scenes.make_oracle(cfg, sc, omp_threads=_threads())
+    ps, solver = scenes.make_ps(sd)
+    o.initialize(); solver.initialize()
+    assert np.array_equal(ps.grid_ids.to_numpy(), o["grid_ids"])
+    assert np.array_equal(ps.pid.to_numpy(), o["pid"])
+    assert np.array_equal(ps.grid_particles_num.to_numpy(), o["grid_particles_num"])
+    solid = o["material"] == 0
+    assert np.allclose(ps.m_V.to_numpy()[solid], o["m_V"][solid], rtol=2e-5)       # static boundary volumes
+    n = 10
+    o.step(n); solver.step(n)
+    err = scenes.rel_l2(scenes.ps_by_pid(ps, "x"), o.by_pid("x"))
+    assert err <= 1e-4, f"C2 position rel-L2 after {n} steps: {err:.3e}"
+    assert np.allclose(scenes.ps_by_pid(ps, "density"), o.by_pid("density"), rtol=5e-5)
+    ps.close()
+
+
+def test_c3_armadillo_equivalent_dynamic_bodies():
+    sd = armadillo_equiv_scene()
+    cfg, sc = scenes.build(sd)
+    assert sc.fluid_particle_num == 246 * 73 * 96 and sorted(sc.dynamic_rigid_ids) == [1, 2, 3]
+    # The reference accumulates the shape-matching sums (5,917 terms per body) in f32; a serial run -- the
+    # oracle's default -- carries ~1e-5 relative summation error per step that drifts the bodies.  The HIP path
+    # reduces in f64.  (1) against the oracle with f64 accumulators the bodies agree tightly; (2) against the
+    # f32-serial oracle the whole system is still inside the 1e-4 budget.
+    o = scenes.make_oracle(cfg, sc, omp_threads=_threads(), rigid_sums_f64=True)
+    o32 = scenes.make_oracle(cfg, sc, omp_threads=_threads())
+    ps, solver = scenes.make_ps(sd)
+    o.initialize(); o32.initialize(); solver.initialize()
+    assert np.array_equal(ps.pid.to_numpy(), o["pid"])
+    assert np.allclose(ps.rigid_rest_cm.to_numpy()[1:4], o["rigid_rest_cm"][1:4], rtol=2e-6)
+    n = 30
+    o.step(n); o32.step(n); solver.step(n)
+    x, x_ref = scenes.ps_by_pid(ps, "x"), o.by_pid("x")
+    err = scenes.rel_l2(x, x_ref)
+    assert err <= 1e-4, f"C3 position rel-L2 after {n} steps: {err:.3e}"
+    rigid = sc.arrays["material"] == 0
+    assert scenes.rel_l2(x[rigid], x_ref[rigid]) <= 2e-5
+    assert scenes.rel_l2(x, o32.by_pid("x")) <= 1e-4
+    v = scenes.ps_by_pid(ps, "v")
+    free_fall = -5.0 - 9.81 * n * 4e-4
+    light = sc.arrays["object_id"] == 3                     # density 300: decelerated hard by the fluid
+    assert v[light, 1].mean() > free_fall + 0.05, "the bodies never touched the fluid: coupling not exercised"
+    assert scenes.rel_l2(v[rigid], o.by_pid("v")[rigid]) <= 2e-3
+    ps.close()
+
+
+def test_c3p_properties_at_full_size():
+    sd = scenes.fluid_only(counts=(246, 74, 96), start=(0.04, 0.04, 0.04), velocity=(0.3, -0.5, 0.2),
+                           domain_end=(5.0, 3.0, 2.0))
+    ps, solver = scenes.make_ps(sd)
+    N = ps.particle_max_num
+    assert N == 1_747_584
+    solver.initialize()
+    solver.step(3)
+    ps.initialize_particle_system()
+    gi = ps.grid_ids.to_numpy()
+    prefix = ps.grid_particles_num.to_numpy()
+    pid = ps.pid.to_numpy()
+    assert np.all(np.diff(gi) >= 0), "sortedness"
+    assert prefix[-1] == N and np.all(np.diff(prefix) >= 0)
+    assert np.array_equal(np.bincount(gi, minlength=prefix.size).cumsum(), prefix), "prefix == cumsum(histogram)"
+    assert np.array_equal(np.sort(pid), np.arange(N)), "the permutation is a bijection"
+    x = ps.x.to_numpy()
+    cell = (x / np.float32(0.04)).astype(np.int64)
+    assert np.array_equal((cell[:, 0] * 75 + cell[:, 1]) * 50 + cell[:, 2], gi), "key == hash(x) after the scatter"
+    ps.initialize_particle_system()                         # idempotence: sorting sorted data is the identity
+    assert np.array_equal(ps.pid.to_numpy(), pid)
+    # pure-fluid pressure forces conserve momentum (symmetric formula, equal m_V)
+    solver.compute_densities()
+    ps.density.from_numpy(ps.density.to_numpy() * np.float32(1.3))
+    ps.acceleration.from_numpy(np.zeros((N, 3), np.float32))
+    solver.compute_pressure_forces()
+    a = ps.acceleration.to_numpy().astype(np.float64)
+    assert np.abs(a.sum(axis=0)).max() < 2e-4 * np.abs(a).sum(axis=0).max()
+    # every gather implementation produces the same densities at full size
+    solver.compute_densities()
+    rho1 = ps.density.to_numpy()
+    from sph_taichi_amd import _lib
+    ps.set_option(_lib.OPT_GATHER_IMPL, 0)
+    solver.compute_densities()
+    assert np.allclose(ps.density.to_numpy(), rho1, rtol=3e-6)
+    ps.close()

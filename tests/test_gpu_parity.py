@@ -16,7 +16,9 @@ F_TOL = {"m_V": 2e-5, "density": 2e-5, "pressure": 2e-3, "acceleration": 5e-4, "
 def _permuted(sc, seed):
     rng = np.random.default_rng(seed)
     perm = rng.permutation(sc.particle_max_num)
-    return {k: v[perm] for k, v in sc.arrays.items()}
+    out = {k: v[perm] for k, v in sc.arrays.items()}
+    out["pid"] = np.arange(sc.particle_max_num, dtype=np.int32)   # persistent id = index at upload time
+    return out
 
 
 def _cmp(name, got, ref, tol):

@@ -104,6 +104,7 @@ def test_sort_invariants():
     perm = rng.permutation(sc.particle_max_num)
     for k in sc.arrays:
         sc.arrays[k] = sc.arrays[k][perm]
+    sc.arrays["pid"] = np.arange(sc.particle_max_num, dtype=np.int32)   # persistent id = index at upload time
     o = scenes.make_oracle(cfg, sc)
     x_before = o["x"].copy()
     o.initialize_particle_system()

@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--fused", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=3, help="CPU-oracle sample size (0 = skip the baseline leg)")
     ap.add_argument("--sweep", action="store_true", help="also time every gather variant (stderr table)")
+    ap.add_argument("--ablate", action="store_true", help="profiling: time the sweeps with sections skipped (stderr)")
+    ap.add_argument("--ablate-mask", type=int, default=0, help="profiling: run the whole bench with this ablation mask (results invalid)")
     args = ap.parse_args()
 
     import torch
@@ -155,6 +157,10 @@ def main():
         return dt, tm
 
     solver.initialize()
+    if args.ablate_mask:
+        solver.step(args.warmup)
+        solver.dt[None] = 0.0
+        ps.set_option(_lib.OPT_DEBUG_ABLATE, args.ablate_mask)
     if args.sweep:
         for impl, shape, fused in [(0, 0, 1), (1, 0, 1), (1, 1, 1), (1, 2, 1), (1, 3, 1), (1, 0, 0)]:
             dt, tm = run(impl, shape, fused, max(args.steps // 4, 10), 5)
@@ -163,6 +169,22 @@ def main():
                   f"sort={tm.sort_ms / k:.3f} neigh={tm.neighbour_ms / k:.3f} force={tm.force_ms / k:.3f} "
                   f"integ={tm.integrate_ms / k:.3f}", file=sys.stderr, flush=True)
 
+    if args.ablate:
+        # same particle state for every variant: sweeps only (no advect), positions frozen by dt = 0
+        solver.step(args.warmup)
+        solver.dt[None] = 0.0
+        for mask, what in [(0, "full"), (1, "no phase 2"), (2, "no list write-out"), (3, "no phase 2, no write-out"),
+                           (4, "no phase 1"), (7, "staging + target setup only"),
+                           (11 + 16, "phase 1 only, branch-free count (no append)"),
+                           (11 + 32, "phase 1 only, no distance math"),
+                           (11 + 48, "phase 1 only, LDS reads + loop only")]:
+            ps.set_option(_lib.OPT_DEBUG_ABLATE, mask)
+            dt, tm = run(args.gather_impl, args.brick_shape, 1, 20, 2)
+            kk = max(tm.steps, 1)
+            print(f"[ablate {mask}] {what:32s} neigh={tm.neighbour_ms / kk:.3f} force={tm.force_ms / kk:.3f}",
+                  file=sys.stderr, flush=True)
+        ps.set_option(_lib.OPT_DEBUG_ABLATE, 0)
+        solver.dt[None] = CFG["timeStepSize"]
     dt, tm = run(args.gather_impl, args.brick_shape, args.fused, args.steps, args.warmup)
     k = max(int(tm.steps), 1)
     ms_per_step = dt / args.steps * 1e3

@@ -106,7 +106,11 @@ enum SphOption {
     SPH_OPT_FUSED_STEP = 2,    /* 1 (default) = sph_step uses the fused density+EOS / force kernels */
     SPH_OPT_BRICK_SHAPE = 3,   /* index into the compiled brick-shape table */
     SPH_OPT_NO_DYNAMIC_SOLIDS = 4 /* 1 = the caller guarantees no dynamic solid particle exists (slab ranks
-                                  cannot know this locally); skips the per-step device count */
+                                  cannot know this locally); skips the per-step device count */,
+    SPH_OPT_DEBUG_ABLATE = 5,  /* profiling only: bit mask of sweep sections to skip (results are then wrong) */
+    SPH_OPT_SLAB_DROP_OUTSIDE = 6 /* slab ranks: a particle whose x cell layer is outside the local grid is hashed to
+                                  a virtual cell G (sorted behind every real cell) instead of being clamped; the
+                                  host then truncates the particle set with sph_truncate */
 };
 
 /* ms accumulated by sph_step since the last sph_reset_timings (HIP events on
@@ -181,6 +185,9 @@ int32_t sph_layer_offsets(SphContext* ctx, const int32_t* layers, int32_t n, int
 /* Keep only [first, first+count) of the current order as the particle set (drops
  * ghosts); must be followed by a sort before any sweep. */
 int32_t sph_select_range(SphContext* ctx, int32_t first, int32_t count);
+/* Shrink the particle set to its first n records without invalidating the neighbour structure
+ * (drops the particles the sort moved into the virtual cell, SPH_OPT_SLAB_DROP_OUTSIDE). */
+int32_t sph_truncate(SphContext* ctx, int32_t n);
 int32_t sph_pack_range(SphContext* ctx, int32_t first, int32_t count, void* device_dst);
 /* Append `count` packed records after the current particles (count += n). */
 int32_t sph_append_records(SphContext* ctx, const void* device_src, int32_t count);

@@ -37,7 +37,8 @@ class SphTimings(C.Structure):
 F_OBJECT_ID, F_X, F_X_0, F_V, F_ACCELERATION, F_M_V, F_M, F_DENSITY, F_PRESSURE, F_MATERIAL, F_COLOR, \
     F_IS_DYNAMIC, F_GRID_IDS, F_GRID_PARTICLES_NUM, F_PID, F_RIGID_REST_CM = range(16)
 # enum SphOption
-OPT_GATHER_IMPL, OPT_TIMING, OPT_FUSED_STEP, OPT_BRICK_SHAPE, OPT_NO_DYNAMIC_SOLIDS = range(5)
+OPT_GATHER_IMPL, OPT_TIMING, OPT_FUSED_STEP, OPT_BRICK_SHAPE, OPT_NO_DYNAMIC_SOLIDS, OPT_DEBUG_ABLATE, \
+    OPT_SLAB_DROP_OUTSIDE = range(7)
 
 ABI_VERSION = 1
 
@@ -76,6 +77,7 @@ SYMBOLS = [
     ("sph_get_particle_count", C.c_int32, [_ctx, C.POINTER(C.c_int32)]),
     ("sph_layer_offsets", C.c_int32, [_ctx, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]),
     ("sph_select_range", C.c_int32, [_ctx, C.c_int32, C.c_int32]),
+    ("sph_truncate", C.c_int32, [_ctx, C.c_int32]),
     ("sph_pack_range", C.c_int32, [_ctx, C.c_int32, C.c_int32, C.c_void_p]),
     ("sph_append_records", C.c_int32, [_ctx, C.c_void_p, C.c_int32]),
     ("sph_sort", C.c_int32, [_ctx]),

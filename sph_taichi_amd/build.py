@@ -10,7 +10,9 @@ CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["sph_api.hip", "sph_sort.hip", "sph_gather.hip", "sph_integrate.hip"]
 HEADERS = [os.path.join(CSRC, "sph_internal.h"), os.path.join(_HERE, "..", "include", "sph_hip.h")]
 LIB = os.path.join(_HERE, "libsph_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall"]
+# -fno-slp-vectorize: the SLP pass packs the x/y lanes of the distance test into v_pk_*_f32, which on gfx950
+# costs extra v_mov + s_nop per pair test (measured: slower than plain v_sub/v_fma)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-fno-slp-vectorize"]
 
 
 def hipcc() -> str:

@@ -21,6 +21,8 @@ DevView sph_view(const SphContext* c) {
     const SphParams& p = c->p;
     d.N = c->N; d.G = c->G;
     d.nx = p.grid_num[0]; d.ny = p.grid_num[1]; d.nz = p.grid_num[2];
+    d.ablate = c->opt_ablate;
+    d.drop_outside = c->opt_drop_outside;
     d.ox = p.cell_origin[0]; d.oy = p.cell_origin[1]; d.oz = p.cell_origin[2];
     d.grid_size = p.grid_size; d.h = p.support_radius; d.inv_h = 1.0f / p.support_radius; d.d = p.particle_diameter;
     d.d2 = p.particle_diameter * p.particle_diameter;  // WCSPH.py:96
@@ -103,7 +105,7 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
         c->own_stream = true;
     }
     const size_t cap = (size_t)c->cap;
-    c->scan_blocks = (c->G + SCAN_TILE - 1) / SCAN_TILE;
+    c->scan_blocks = (c->G + 1 + SCAN_TILE - 1) / SCAN_TILE;  // + the virtual cell G of slab mode
     int rc = 0;
     for (int s = 0; s < 2 && !rc; ++s) {
         rc = rc ? rc : alloc_dev(c, (void**)&c->xm[s], cap * 16);
@@ -170,6 +172,8 @@ int32_t sph_set_option(SphContext* c, int32_t option, int32_t value) {
         case SPH_OPT_FUSED_STEP: c->opt_fused = value ? 1 : 0; return 0;
         case SPH_OPT_BRICK_SHAPE: if (value < 0 || value > 3) return sph_fail(c, SPH_E_INVALID, "brick shape must be 0..3"); c->opt_brick_shape = value; return 0;
         case SPH_OPT_NO_DYNAMIC_SOLIDS: c->opt_no_dynamic = value ? 1 : 0; c->n_dyn_host = -1; return 0;
+        case SPH_OPT_DEBUG_ABLATE: c->opt_ablate = value; return 0;
+        case SPH_OPT_SLAB_DROP_OUTSIDE: c->opt_drop_outside = value ? 1 : 0; return 0;
     }
     return sph_fail(c, SPH_E_INVALID, "unknown option");
 }
@@ -524,6 +528,12 @@ int32_t sph_select_range(SphContext* c, int32_t first, int32_t count) {
     c->N = count;
     c->have_keys = c->have_prefix = c->sorted = false;
     c->n_dyn_host = -1;
+    return 0;
+}
+
+int32_t sph_truncate(SphContext* c, int32_t n) {
+    if (!c || n < 0 || n > c->N) return sph_fail(c, SPH_E_INVALID, "sph_truncate: out of range");
+    c->N = n;
     return 0;
 }
 

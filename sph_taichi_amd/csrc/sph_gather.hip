@@ -307,9 +307,11 @@ struct BrickCfg {
     static constexpr int NZS = BZ + 3;  // cell-end entries per column (start + BZ+2 ends)
     static constexpr int PER = (CAP + TPB - 1) / TPB;  // staged records per lane
     // LDS carve (bytes, every offset a multiple of 16)
-    static constexpr int OFF_XY = 0;
-    static constexpr int OFF_ZW = OFF_XY + CAP * 8;
-    static constexpr int OFF_CE = OFF_ZW + CAP * 8;
+    static constexpr int OFF_X = 0;
+    static constexpr int OFF_Y = OFF_X + CAP * 4;
+    static constexpr int OFF_Z = OFF_Y + CAP * 4;
+    static constexpr int OFF_W = OFF_Z + CAP * 4;
+    static constexpr int OFF_CE = OFF_W + CAP * 4;
     static constexpr int OFF_COLG = OFF_CE + ((NCOL * NZS * 4 + 15) / 16) * 16;
     static constexpr int OFF_COLS = OFF_COLG + 64 * 4;
     static constexpr int OFF_TG = OFF_COLS + 80 * 4;
@@ -328,8 +330,10 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
                                                       int bricks_per_xcd, unsigned short* __restrict__ glist,
                                                       unsigned char* __restrict__ gcnt, int cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* sXY = reinterpret_cast<float2*>(smem + CFG::OFF_XY);
-    float2* sZW = reinterpret_cast<float2*>(smem + CFG::OFF_ZW);
+    float* sX = reinterpret_cast<float*>(smem + CFG::OFF_X);
+    float* sY = reinterpret_cast<float*>(smem + CFG::OFF_Y);
+    float* sZ = reinterpret_cast<float*>(smem + CFG::OFF_Z);
+    float* sW = reinterpret_cast<float*>(smem + CFG::OFF_W);
     int* sCE = reinterpret_cast<int*>(smem + CFG::OFF_CE);      // [NCOL][NZS] raw cell_end values of the shell
     int* sColG = reinterpret_cast<int*>(smem + CFG::OFF_COLG);  // global start of the column segment
     int* sColS = reinterpret_cast<int*>(smem + CFG::OFF_COLS);  // LDS start of the column segment (+ total at [64])
@@ -403,8 +407,7 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
         for (int u = 0; u < CFG::PER; ++u) {
             const int idx = tid + u * TPB;
             if (idx < total) {
-                sXY[idx] = make_float2(buf[u].x, buf[u].y);
-                sZW[idx] = make_float2(buf[u].z, buf[u].w);
+                sX[idx] = buf[u].x; sY[idx] = buf[u].y; sZ[idx] = buf[u].z; sW[idx] = buf[u].w;
             }
         }
     }
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
         bool walk = g && overflow;
         int cnt = 0;
         const int li = sColS[col] + (gi - sColG[col]);  // own LDS slot
-        if (g && !overflow && !mode_reads_list<MODE>()) {
+        if (g && !overflow && !mode_reads_list<MODE>() && !(d.ablate & 4)) {
             const int ix = sx0 + col / ncy, iy = sy0 + col % ncy;
             const int cz = d.key[gi] % d.nz;
             const int klo = (cz > 0 ? cz - 1 : 0) - sz0;  // first cell of the z-run, shell-relative
@@ -440,6 +443,7 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
                         uy = fminf(fmaxf(t.y - (float)(iy + d.oy) * d.grid_size, 0.0f), d.grid_size),
                         uz = fminf(fmaxf(t.z - (float)(cz + d.oz) * d.grid_size, 0.0f), d.grid_size);
             const float gzlo = uz * uz, gzhi = (d.grid_size - uz) * (d.grid_size - uz);
+            const bool abl_noappend = d.ablate & 16, abl_nomath = d.ablate & 32;
             char* lp = reinterpret_cast<char*>(sList) + tid * 2;
             char* const lp0 = lp;
             char* const lp_guard = lp + CFG::LISTCAP * TPB * 2;
@@ -462,11 +466,13 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
                     const int lo = sCE[ncol * CFG::NZS + kl] + rel;
                     const int hi = sCE[ncol * CFG::NZS + kh + 1] + rel;
                     const unsigned tag = (unsigned)ncol << 11;
-#define SPH_FILTER(XY, ZW, jj)                                                       \
+#define SPH_FILTER(X_, Y_, Z_, jj)                                                   \
     {                                                                                \
-        const float rx_ = t.x - (XY).x, ry_ = t.y - (XY).y, rz_ = t.z - (ZW).x;      \
-        const float r2_ = rx_ * rx_ + ry_ * ry_ + rz_ * rz_;                         \
-        if (r2_ < h2p) {                                                             \
+        const float rx_ = t.x - (X_), ry_ = t.y - (Y_), rz_ = t.z - (Z_);            \
+        const float r2_ = abl_nomath ? rx_ : rx_ * rx_ + ry_ * ry_ + rz_ * rz_;      \
+        if (abl_noappend) {                                                          \
+            lp += (r2_ < h2p) ? TPB * 2 : 0;                                         \
+        } else if (r2_ < h2p) {                                                      \
             *reinterpret_cast<unsigned short*>(lp < lp_guard ? lp : lp_guard) =      \
                 (unsigned short)(tag | (unsigned)(jj));                              \
             lp += TPB * 2;                                                           \
@@ -474,21 +480,21 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
     }
                     int j = lo;
                     for (; j + 4 <= hi; j += 4) {
-                        const float2 p0 = sXY[j], p1 = sXY[j + 1], p2 = sXY[j + 2], p3 = sXY[j + 3];
-                        const float2 q0 = sZW[j], q1 = sZW[j + 1], q2 = sZW[j + 2], q3 = sZW[j + 3];
-                        SPH_FILTER(p0, q0, j) SPH_FILTER(p1, q1, j + 1) SPH_FILTER(p2, q2, j + 2)
-                        SPH_FILTER(p3, q3, j + 3)
+                        const float x0 = sX[j], x1 = sX[j + 1], x2 = sX[j + 2], x3 = sX[j + 3];
+                        const float y0 = sY[j], y1 = sY[j + 1], y2 = sY[j + 2], y3 = sY[j + 3];
+                        const float z0 = sZ[j], z1 = sZ[j + 1], z2 = sZ[j + 2], z3 = sZ[j + 3];
+                        SPH_FILTER(x0, y0, z0, j) SPH_FILTER(x1, y1, z1, j + 1) SPH_FILTER(x2, y2, z2, j + 2)
+                        SPH_FILTER(x3, y3, z3, j + 3)
                     }
                     for (; j < hi; ++j) {
-                        const float2 p0 = sXY[j];
-                        const float2 q0 = sZW[j];
-                        SPH_FILTER(p0, q0, j)
+                        const float x0 = sX[j], y0 = sY[j], z0 = sZ[j];
+                        SPH_FILTER(x0, y0, z0, j)
                     }
 #undef SPH_FILTER
                 }
             }
             cnt = (int)(lp - lp0) / (TPB * 2);
-            if (cnt > CFG::LISTCAP) walk = true;  // list overflow (extreme compression): exact slow path
+            if (cnt > CFG::LISTCAP && !(d.ablate & 8)) walk = true;  // list overflow (extreme compression): exact slow path
         }
         if (mode_reads_list<MODE>() && g && !overflow) {
             cnt = gcnt[gi];
@@ -496,10 +502,10 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
         }
         if (mode_writes_list<MODE>() && g) {
             gcnt[gi] = (unsigned char)(walk ? SPH_CNT_WALK : cnt);
-            if (!walk)
+            if (!walk && !(d.ablate & 2))
                 for (int k = 0; k < cnt; ++k) glist[(size_t)k * cap + gi] = sList[k * TPB + tid];
         }
-        if (g && !walk) {
+        if (g && !walk && !(d.ablate & 1)) {
             // phase 2: pair physics over the list; the next entry's records are prefetched
             unsigned e1 = 0, e2 = 0;  // entries k+1 and k+2
             if (mode_reads_list<MODE>()) {
@@ -509,25 +515,25 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
                 if (cnt > 0) e1 = sList[tid];
                 if (cnt > 1) e2 = sList[TPB + tid];
             }
-            float2 XYn = make_float2(0.f, 0.f), ZWn = XYn;
+            float4 An = make_float4(0.f, 0.f, 0.f, 0.f);
             float4 Bn = make_float4(0.f, 0.f, 0.f, 0.f), Cn = Bn;
             int gn = 0, jn = -1;
             if (cnt > 0) {
                 jn = e1 & 2047;
                 const int c2 = e1 >> 11;
-                XYn = sXY[jn]; ZWn = sZW[jn];
+                An = make_float4(sX[jn], sY[jn], sZ[jn], sW[jn]);
                 gn = sColG[c2] + (jn - sColS[c2]);
                 if (mode_needs_B<MODE>()) Bn = d.vf[gn];
                 if (mode_needs_C<MODE>()) Cn = load_C_global<MODE>(d, gn);
             }
             for (int k = 0; k < cnt; ++k) {
-                const float2 XY = XYn, ZW = ZWn;
+                const float4 A = An;
                 const float4 B = Bn, Cc = Cn;
                 const int gj = gn, j = jn;
                 if (k + 1 < cnt) {
                     jn = e2 & 2047;
                     const int c2 = e2 >> 11;
-                    XYn = sXY[jn]; ZWn = sZW[jn];
+                    An = make_float4(sX[jn], sY[jn], sZ[jn], sW[jn]);
                     gn = sColG[c2] + (jn - sColS[c2]);
                     if (mode_needs_B<MODE>()) Bn = d.vf[gn];
                     if (mode_needs_C<MODE>()) Cn = load_C_global<MODE>(d, gn);
@@ -535,12 +541,12 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
                         e2 = mode_reads_list<MODE>() ? (unsigned)glist[(size_t)(k + 2) * cap + gi]
                                                      : (unsigned)sList[(k + 2) * TPB + tid];
                 }
-                const float rx = t.x - XY.x, ry = t.y - XY.y, rz = t.z - ZW.x;
+                const float rx = t.x - A.x, ry = t.y - A.y, rz = t.z - A.z;
                 const float r2 = rx * rx + ry * ry + rz * rz;
                 const float rinv = sph_rsq(r2);
                 const float rn = r2 * rinv;
                 if (rn < d.h && j != li)  // particle_system.py:385
-                    pair_physics<MODE>(d, t, rx, ry, rz, r2, rn, rinv, make_float4(XY.x, XY.y, ZW.x, ZW.y), B, Cc, gj);
+                    pair_physics<MODE>(d, t, rx, ry, rz, r2, rn, rinv, A, B, Cc, gj);
             }
         }
         if (walk) {

@@ -29,6 +29,8 @@ struct DevView {
     int N, G;
     int nx, ny, nz;
     int ox, oy, oz;  // cell_origin (multi-GPU slabs)
+    int drop_outside;  // slab mode: x layer outside the local grid -> virtual cell G
+    int ablate;      // debug: bit0 skip phase 2, bit1 skip list write-out, bit2 skip phase 1 (profiling only)
     float grid_size, h, inv_h, d, d2, m_V0, rho0, stiffness, exponent, sigma, dt;
     float gx, gy, gz;
     float domx, domy, domz, pad;
@@ -82,7 +84,7 @@ struct SphContext {
     size_t stage_bytes;
     bool have_keys, have_prefix, sorted;
     // options
-    int opt_gather_impl, opt_timing, opt_fused, opt_brick_shape, opt_no_dynamic;
+    int opt_gather_impl, opt_timing, opt_fused, opt_brick_shape, opt_no_dynamic, opt_ablate, opt_drop_outside;
     // timing
     hipEvent_t ev[SPH_MAX_TIMED_STEPS][5];
     int ev_used;

@@ -32,6 +32,10 @@ __global__ __launch_bounds__(TPB) void k_hash_histogram(DevView d, int* __restri
         const int cy = sph_cell_coord(p.y, d.grid_size, d.oy, d.ny);
         const int cz = sph_cell_coord(p.z, d.grid_size, d.oz, d.nz);
         c = sph_flatten(d, cx, cy, cz);
+        if (d.drop_outside) {  // slab rank: not in any local x layer -> virtual cell G, sorted behind everything
+            const int raw = (int)(p.x / d.grid_size) - d.ox;
+            if (raw < 0 || raw >= d.nx) c = d.G;
+        }
         d.key[i] = c;  // particle_system.py:315
     }
     // run detection inside the wave (wavefront ballot primitive)
@@ -150,8 +154,11 @@ __global__ __launch_bounds__(TPB) void k_stable_scatter(DevView d, const int* __
     const int c = d.key[i];
     const int b = c > 0 ? d.cell_end[c - 1] : 0;
     const int e = d.cell_end[c];
-    int rank = 0;
-    for (int t = b; t < e; ++t) rank += (idx_unstable[t] < i) ? 1 : 0;
+    int rank = s - b;  // virtual cell G (dropped slab strays): any order will do, and the cell can be huge
+    if (c != d.G) {
+        rank = 0;
+        for (int t = b; t < e; ++t) rank += (idx_unstable[t] < i) ? 1 : 0;
+    }
     const int dst = b + rank;  // == grid_ids_new[i] of a serial run (particle_system.py:330)
     const float4 xm = d.xm[i];
     const float4 vf = d.vf[i];
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(TPB) void k_stable_scatter(DevView d, const int* __
     aux_out[dst] = aux;
     key_out[dst] = c;
     if (SORT_ACC) acc_out[dst] = d.acc[i];
-    if (sph_is_dynamic_rigid(__float_as_int(vf.w))) dyn_list[atomicAdd(dyn_count, 1)] = dst;
+    if (c != d.G && sph_is_dynamic_rigid(__float_as_int(vf.w))) dyn_list[atomicAdd(dyn_count, 1)] = dst;
 }
 
 // ---------------------------------------------------------------------------

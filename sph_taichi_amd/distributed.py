@@ -6,16 +6,21 @@ particle_system.py:294) at planes chosen from the per-layer particle histogram s
 every rank owns about N/world particles.  Rank r owns global cell layers
 [X_r, X_r+1); its local grid adds HALO = 2 ghost layers on each side.
 
-One exchange per step.  After integrating, a rank sorts its owned particles; the
-sort makes every set of x-layers one contiguous index range, so
+One exchange and ONE sort per step.  The sort makes every set of x-layers one
+contiguous index range, and a particle moves at most one cell per step, so after
+the sweeps of step n (positions advanced, order still that of step n's sort)
 
-    to the left  neighbour:  local layers [HALO-1, 2*HALO)   = leavers + first HALO owned layers
-    to the right neighbour:  local layers [nx-2*HALO, nx-HALO+1)
+    to the left  neighbour:  old local layers [HALO, 2*HALO+1)
+    to the right neighbour:  old local layers [nx-2*HALO-1, nx-HALO)
 
-are two contiguous ranges of packed 48-byte records (sph_pack_range: plain D2D
-copies, no pack kernel).  The receiver appends them and sorts again; ownership is
-implied by position (owned <=> local layer in [HALO, nx-HALO)): a leaver becomes
-the neighbour's particle and stays behind as a ghost.  With a 2-layer halo the
+contain every particle that can be a ghost or an immigrant of that neighbour in
+step n+1.  They are two contiguous ranges of packed 48-byte records whose offsets
+the host already knows (sph_pack_range: plain D2D copies, no pack kernel, no
+sync).  The receiver keeps its previously owned range, appends what arrives and
+sorts once; ownership is implied by the NEW position (owned <=> local layer in
+[HALO, nx-HALO)): a leaver becomes the neighbour's particle and stays behind as
+a ghost; strays that end up outside the local grid hash to a virtual cell behind
+all real cells and are truncated away.  With a 2-layer halo the
 first ghost layer's densities/pressures are computed locally and correctly, so no
 second message is needed inside the step; the reaction of the two-way coupling on
 a rigid particle is accumulated by its owner from its (ghost-layer-1) fluid
@@ -150,6 +155,7 @@ class SlabSolver:
         self.ps.set_option(_lib.OPT_BRICK_SHAPE, brick_shape)
         dyn_blocks = [b for b in cfg.get_rigid_blocks() if b.get("isDynamic")]
         self.ps.set_option(_lib.OPT_NO_DYNAMIC_SOLIDS, 0 if dyn_blocks else 1)
+        self.ps.set_option(_lib.OPT_SLAB_DROP_OUTSIDE, 1)
         self.solver = self.ps.build_solver()
         self.nx_local = self.x_hi - self.x_lo + 2 * HALO
         self.capacity = capacity
@@ -158,6 +164,7 @@ class SlabSolver:
         self.recv_buf = {side: torch.empty(nbuf, dtype=torch.uint8, device=self.tdev) for side in ("L", "R")}
         self.nbuf = nbuf
         self.owned_range = None     # (first, count) of the owned particles in the current order
+        self.off = None
         self.has_left, self.has_right = rank > 0, rank < world - 1
         self.stats = {"sent": 0, "received": 0}
 
@@ -176,37 +183,49 @@ class SlabSolver:
         return self.recv_buf[side]
 
     # -- the two halves of a step around the exchange -------------------------
+    # One sort per step.  `self.off` holds, for the CURRENT order (the one the last sort produced, whose
+    # positions the sweeps have since advanced), the record offsets of the layer boundaries
+    #   [HALO, 2*HALO+1, nx-2*HALO-1, nx-HALO]
+    # so the ranges to send and the owned range are known on the host without touching the device.
     def pre_exchange(self):
-        """Drop last step's ghosts, sort the owned particles, pack the two boundary ranges."""
+        """Pack the boundary layers of the current order for both neighbours (no sort, no sync)."""
         ps = self.ps
-        if self.owned_range is not None:
-            ps._call("sph_select_range", self.owned_range[0], self.owned_range[1])
-        ps._call("sph_sort")
-        nx = self.nx_local
-        o = self._offsets([HALO - 1, 2 * HALO, nx - 2 * HALO, nx - HALO + 1, nx])
-        if o[0] != 0 or o[4] != o[3]:
-            raise RuntimeError(f"rank {self.rank}: a particle crossed more than one cell layer in one step")
-        nL, nR = (o[1] - o[0]) if self.has_left else 0, (o[3] - o[2]) if self.has_right else 0
+        if self.off is None:          # first call: nothing sorted yet -> sort the initial (owned) particles
+            ps._call("sph_sort")
+            self._after_sort()
+        o = self.off
+        nL = (o[1] - o[0]) if self.has_left else 0        # old layers [HALO, 2*HALO+1)
+        nR = (o[3] - o[2]) if self.has_right else 0       # old layers [nx-2*HALO-1, nx-HALO)
         for side, first, n in (("L", o[0], nL), ("R", o[2], nR)):
             if n * RECORD_BYTES > self.send_buf[side].numel():
-                self.send_buf[side] = self.torch.empty(n * RECORD_BYTES, dtype=self.torch.uint8, device=self.tdev)
+                self.send_buf[side] = self.torch.empty(int(1.25 * n) * RECORD_BYTES, dtype=self.torch.uint8,
+                                                       device=self.tdev)
             if n > 0:
                 ps._call("sph_pack_range", first, n, C.c_void_p(self.send_buf[side].data_ptr()))
         self.stats["sent"] += nL + nR
         return self.send_buf["L"], nL, self.send_buf["R"], nR
 
     def post_exchange(self, recv_left, n_left, recv_right, n_right, sweeps=True):
-        """Append the neighbours' ranges (ghosts + immigrants), sort, run the step's sweeps."""
+        """Keep the previously owned range, append the neighbours' boundary layers, sort once (position
+        decides ownership; strays outside the local grid fall into the virtual cell and are dropped), sweep."""
         ps = self.ps
+        o = self.off
+        ps._call("sph_select_range", o[0], o[3] - o[0])   # old owned layers [HALO, nx-HALO)
         for buf, n in ((recv_left, n_left), (recv_right, n_right)):
             if n > 0:
                 ps._call("sph_append_records", C.c_void_p(buf.data_ptr()), n)
         self.stats["received"] += n_left + n_right
         ps._call("sph_sort")
-        o = self._offsets([HALO, self.nx_local - HALO])
-        self.owned_range = (o[0], o[1] - o[0])
+        self._after_sort()
         if sweeps:
             ps._call("sph_sweeps")
+
+    def _after_sort(self):
+        nx = self.nx_local
+        o = self._offsets([HALO, 2 * HALO + 1, nx - 2 * HALO - 1, nx - HALO, nx])
+        self.ps._call("sph_truncate", o[4])               # drop the virtual cell
+        self.off = o[:4]
+        self.owned_range = (o[0], o[3] - o[0])
 
     # -- torch.distributed driver --------------------------------------------
     def attach(self, transport):

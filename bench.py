@@ -174,10 +174,7 @@ def main():
         solver.step(args.warmup)
         solver.dt[None] = 0.0
         for mask, what in [(0, "full"), (1, "no phase 2"), (2, "no list write-out"), (3, "no phase 2, no write-out"),
-                           (4, "no phase 1"), (7, "staging + target setup only"),
-                           (11 + 16, "phase 1 only, branch-free count (no append)"),
-                           (11 + 32, "phase 1 only, no distance math"),
-                           (11 + 48, "phase 1 only, LDS reads + loop only")]:
+                           (4, "no phase 1"), (7, "staging + target setup only")]:
             ps.set_option(_lib.OPT_DEBUG_ABLATE, mask)
             dt, tm = run(args.gather_impl, args.brick_shape, 1, 20, 2)
             kk = max(tm.steps, 1)
@@ -191,8 +188,26 @@ def main():
     steps_per_s = args.steps / dt
     value = steps_per_s * N / REF_PARTICLES
     force_ms = tm.force_ms / k
-    alg_bytes = 60.0 * N + 4.0 * G                      # fused force sweep, per launch
-    achieved = alg_bytes / (force_ms * 1e-3) / 1e9 if force_ms > 0 else 0.0
+    neigh_ms = tm.neighbour_ms / k
+    # Per-launch algorithmic bytes: density+EOS sweep 32 N + 4 G, fused force sweep 60 N + 4 G.  With no
+    # dynamic rigid body each phase is exactly one launch, so the HIP-event phase time is that kernel's duration.
+    kernels = {
+        "k_gather_brick<GM_DENSITY_EOS>": (32.0 * N + 4.0 * G, neigh_ms),
+        "k_gather_brick<GM_FORCE_FUSED>": (60.0 * N + 4.0 * G, force_ms),
+    }
+    if not args.gather_impl:
+        kernels = {k_.replace("brick", "simple"): v for k_, v in kernels.items()}
+    dominant = max(kernels, key=lambda k_: kernels[k_][1])
+    alg_bytes, dom_ms = kernels[dominant]
+    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    traffic = None
+    try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (same workload / variant only)
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if pm["workload"] == args.workload and args.gather_impl == 1 and args.brick_shape == 0 and args.fused == 1:
+            kk = pm["kernels"][dominant]
+            traffic = kk["fetch_kb"] * 1024 * 2 + kk["write_kb"] * 1024
+    except Exception:
+        traffic = None
     line = {
         "metric": "WCSPH steps/sec at 1.74 M particles (+ ms/step breakdown sort/neighbour/force)",
         "value": round(value, 3), "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -201,14 +216,18 @@ def main():
         "config": {"workload": args.workload, "particles": N, "cells": G, "dt": CFG["timeStepSize"],
                    "gather_impl": args.gather_impl, "brick_shape": args.brick_shape, "fused": args.fused,
                    "parallelism": "1 GPU"},
-        "breakdown_ms": {"sort": round(tm.sort_ms / k, 4), "neighbour": round(tm.neighbour_ms / k, 4),
+        "breakdown_ms": {"sort": round(tm.sort_ms / k, 4), "neighbour": round(neigh_ms, 4),
                          "force": round(force_ms, 4), "integrate": round(tm.integrate_ms / k, 4),
                          "sum_of_phases": round(tm.total_ms / k, 4)},
         "steps_per_s_job": round(steps_per_s, 3),
-        "roofline": {"kernel": "k_gather_brick<GM_FORCE_FUSED>" if args.gather_impl else "k_gather_simple<GM_FORCE_FUSED>",
-                     "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                     "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(force_ms, 4)},
+        "roofline": {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                     "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4),
+                     "note": "gather sweeps are VALU/LDS-bound, not HBM-bound (DESIGN.md section 4); "
+                             "traffic = rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch (profiles/pmc_traffic.json)"},
+        "roofline_kernels": {k_: {"alg_bytes": v[0], "avg_launch_ms": round(v[1], 4),
+                                  "achieved_GBs": round(v[0] / (v[1] * 1e-3) / 1e9, 2) if v[1] > 0 else 0.0}
+                             for k_, v in kernels.items()},
     }
     # secondary: whole-step algorithmic bytes (360 N + 20 G) against the same peak
     step_bytes = 360.0 * N + 20.0 * G

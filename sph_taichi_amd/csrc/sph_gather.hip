@@ -443,7 +443,6 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
                         uy = fminf(fmaxf(t.y - (float)(iy + d.oy) * d.grid_size, 0.0f), d.grid_size),
                         uz = fminf(fmaxf(t.z - (float)(cz + d.oz) * d.grid_size, 0.0f), d.grid_size);
             const float gzlo = uz * uz, gzhi = (d.grid_size - uz) * (d.grid_size - uz);
-            const bool abl_noappend = d.ablate & 16, abl_nomath = d.ablate & 32;
             char* lp = reinterpret_cast<char*>(sList) + tid * 2;
             char* const lp0 = lp;
             char* const lp_guard = lp + CFG::LISTCAP * TPB * 2;
@@ -469,10 +468,8 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
 #define SPH_FILTER(X_, Y_, Z_, jj)                                                   \
     {                                                                                \
         const float rx_ = t.x - (X_), ry_ = t.y - (Y_), rz_ = t.z - (Z_);            \
-        const float r2_ = abl_nomath ? rx_ : rx_ * rx_ + ry_ * ry_ + rz_ * rz_;      \
-        if (abl_noappend) {                                                          \
-            lp += (r2_ < h2p) ? TPB * 2 : 0;                                         \
-        } else if (r2_ < h2p) {                                                      \
+        const float r2_ = rx_ * rx_ + ry_ * ry_ + rz_ * rz_;                         \
+        if (r2_ < h2p) {                                                             \
             *reinterpret_cast<unsigned short*>(lp < lp_guard ? lp : lp_guard) =      \
                 (unsigned short)(tag | (unsigned)(jj));                              \
             lp += TPB * 2;                                                           \

@@ -76,25 +76,42 @@ class TorchTransport:
         self.device = device
         self.cpu_staging = dist.get_backend() == "gloo"
 
+    def _neighbours(self):
+        left = self.rank - 1 if self.rank > 0 else None
+        right = self.rank + 1 if self.rank < self.world - 1 else None
+        return left, right
+
+    def start_counts(self, n_left, n_right):
+        """Post (non-blocking) the record counts of the NEXT exchange.  The sender knows them as soon as its
+        sort is done, a whole sweep phase before the payload exists, so this round trip leaves the critical path."""
+        torch, dist = self.torch, self.dist
+        left, right = self._neighbours()
+        dev = "cpu" if self.cpu_staging else self.device
+        out = {left: torch.tensor([n_left], dtype=torch.int64, device=dev),
+               right: torch.tensor([n_right], dtype=torch.int64, device=dev)}
+        cin = {p: torch.zeros(1, dtype=torch.int64, device=dev) for p in (left, right) if p is not None}
+        ops = []
+        for p in (left, right):
+            if p is not None:
+                ops.append(dist.P2POp(dist.isend, out[p], p))
+                ops.append(dist.P2POp(dist.irecv, cin[p], p))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        self._pending = (works, out, cin, (n_left, n_right))
+
     def exchange(self, send_left, n_left, send_right, n_right, alloc):
         """send_* : uint8 device tensors (or None at the domain ends) holding n_* records.
         Returns (recv_left, n, recv_right, n)."""
         torch, dist = self.torch, self.dist
-        left = self.rank - 1 if self.rank > 0 else None
-        right = self.rank + 1 if self.rank < self.world - 1 else None
-        dev = "cpu" if self.cpu_staging else self.device
-        # 1) counts
-        cnt_out = {left: torch.tensor([n_left], dtype=torch.int64, device=dev),
-                   right: torch.tensor([n_right], dtype=torch.int64, device=dev)}
-        cnt_in = {p: torch.zeros(1, dtype=torch.int64, device=dev) for p in (left, right) if p is not None}
-        ops = []
-        for p in (left, right):
-            if p is not None:
-                ops.append(dist.P2POp(dist.isend, cnt_out[p], p))
-                ops.append(dist.P2POp(dist.irecv, cnt_in[p], p))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+        left, right = self._neighbours()
+        # 1) counts: posted ahead by start_counts, or exchanged now (first call)
+        if getattr(self, "_pending", None) is None:
+            self.start_counts(n_left, n_right)
+        works, _out, cnt_in, announced = self._pending
+        self._pending = None
+        if announced != (n_left, n_right):
+            raise RuntimeError(f"rank {self.rank}: announced counts {announced} != sent counts {(n_left, n_right)}")
+        for w in works:
+            w.wait()
         n_in = {p: int(cnt_in[p].item()) for p in cnt_in}
         # 2) payload
         bufs = {}
@@ -205,7 +222,7 @@ class SlabSolver:
         self.stats["sent"] += nL + nR
         return self.send_buf["L"], nL, self.send_buf["R"], nR
 
-    def post_exchange(self, recv_left, n_left, recv_right, n_right, sweeps=True):
+    def post_exchange(self, recv_left, n_left, recv_right, n_right, sweeps=True, announce=False):
         """Keep the previously owned range, append the neighbours' boundary layers, sort once (position
         decides ownership; strays outside the local grid fall into the virtual cell and are dropped), sweep."""
         ps = self.ps
@@ -217,6 +234,8 @@ class SlabSolver:
         self.stats["received"] += n_left + n_right
         ps._call("sph_sort")
         self._after_sort()
+        if announce:                  # the next exchange's sizes are known now: tell the neighbours early
+            self.transport.start_counts(*self.next_counts())
         if sweeps:
             ps._call("sph_sweeps")
 
@@ -237,7 +256,11 @@ class SlabSolver:
             self.ps.sync()      # the packed ranges are written on the context's stream, RCCL reads on torch's
             rL, mL, rR, mR = self.transport.exchange(sL if self.has_left else None, nL,
                                                      sR if self.has_right else None, nR, self._alloc_recv)
-            self.post_exchange(rL, mL, rR, mR, sweeps=sweeps)
+            self.post_exchange(rL, mL, rR, mR, sweeps=sweeps, announce=True)
+
+    def next_counts(self):
+        o = self.off
+        return ((o[1] - o[0]) if self.has_left else 0, (o[3] - o[2]) if self.has_right else 0)
 
     def initialize(self):
         """SPHBase.initialize() (sph_base.py:80-85) for a slab: neighbour structure with halos, then the

@@ -23,8 +23,11 @@ def main():
     if mode == "transport":
         tr = TorchTransport("cpu")
         ok = True
-        for it in range(4):
+        cnt = lambda it: ((3 + rank + it) % 5 if rank > 0 else 0, (7 * rank + 2 * it) % 6 if rank < world - 1 else 0)
+        for it in range(5):
             nL, nR = (3 + rank + it) % 5, (7 * rank + 2 * it) % 6          # ragged, sometimes zero
+            if it >= 2:         # from the third round on the counts were announced one round ahead
+                assert tr._pending is not None
             mk = lambda n, tag: torch.full((max(n, 1) * RECORD_BYTES,), tag, dtype=torch.uint8)
             alloc = lambda from_left, n: torch.zeros(n * RECORD_BYTES, dtype=torch.uint8)
             rL, mL, rR, mR = tr.exchange(mk(nL, 10 + rank) if rank > 0 else None, nL if rank > 0 else 0,
@@ -36,6 +39,8 @@ def main():
             if rank < world - 1:
                 exp = (3 + rank + 1 + it) % 5
                 ok &= mR == exp and (exp == 0 or bool((rR[: exp * RECORD_BYTES] == 10 + rank + 1).all()))
+            if it >= 1 and it < 4:
+                tr.start_counts(*cnt(it + 1))
         flag = torch.tensor([1 if ok else 0])
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if rank == 0:

@@ -299,6 +299,9 @@ template <int MODE>
 __host__ __device__ constexpr bool mode_writes_list() { return MODE == GM_DENSITY_EOS; }
 template <int MODE>
 __host__ __device__ constexpr bool mode_reads_list() { return MODE == GM_FORCE_FUSED; }
+// sweeps whose pair term needs only (r, m_V_j): evaluated inside the filter's emission loop
+template <int MODE>
+__host__ __device__ constexpr bool mode_inline_physics() { return MODE == GM_DENSITY || MODE == GM_DENSITY_EOS; }
 
 template <int BX_, int BY_, int BZ_, int CAP_, int LISTCAP_>
 struct BrickCfg {
@@ -306,23 +309,22 @@ struct BrickCfg {
     static constexpr int NCOL = (BX + 2) * (BY + 2);
     static constexpr int NZS = BZ + 3;  // cell-end entries per column (start + BZ+2 ends)
     static constexpr int PER = (CAP + TPB - 1) / TPB;  // staged records per lane
-    // LDS carve (bytes, every offset a multiple of 16)
-    static constexpr int OFF_X = 0;
-    static constexpr int OFF_Y = OFF_X + CAP * 4;
-    static constexpr int OFF_Z = OFF_Y + CAP * 4;
-    static constexpr int OFF_W = OFF_Z + CAP * 4;
-    static constexpr int OFF_CE = OFF_W + CAP * 4;
-    static constexpr int OFF_COLG = OFF_CE + ((NCOL * NZS * 4 + 15) / 16) * 16;
-    static constexpr int OFF_COLS = OFF_COLG + 64 * 4;
-    static constexpr int OFF_TG = OFF_COLS + 80 * 4;
-    static constexpr int OFF_TOFF = OFF_TG + 64 * 4;
-    static constexpr int OFF_LIST = OFF_TOFF + 80 * 4;
-    static constexpr int BYTES_NOLIST = OFF_LIST;
-    static constexpr int BYTES_LIST = OFF_LIST + (LISTCAP + 1) * TPB * 2;  // +1 guard row for overflowing appends
+    // LDS carve (bytes, every offset a multiple of 16).  Filtering sweeps stage float4 (-2x', -2y', -2z', |x'|^2)
+    // + a separate m_V array (20 B per record); the list-reading force sweep needs no |x'|^2 and stages
+    // float4 (-2x', -2y', -2z', m_V) only (16 B per record -> one more workgroup per CU).
+    static constexpr int OFF_Q = 0;
+    static constexpr int off_w(bool has_w) { return OFF_Q + CAP * 16; }
+    static constexpr int off_ce(bool has_w) { return off_w(has_w) + (has_w ? CAP * 4 : 0); }
+    static constexpr int off_colg(bool has_w) { return off_ce(has_w) + ((NCOL * NZS * 4 + 15) / 16) * 16; }
+    static constexpr int off_cols(bool has_w) { return off_colg(has_w) + 64 * 4; }
+    static constexpr int off_tg(bool has_w) { return off_cols(has_w) + 80 * 4; }
+    static constexpr int off_toff(bool has_w) { return off_tg(has_w) + 64 * 4; }
+    static constexpr int bytes(bool has_w) { return off_toff(has_w) + 80 * 4; }
     static_assert(NCOL <= 32, "column id must fit 5 bits of a list entry");
     static_assert(CAP <= 2048, "LDS slot must fit 11 bits of a list entry");
-    static_assert(LISTCAP < SPH_CNT_WALK, "gcnt is a byte");
-    static_assert(BYTES_LIST <= 54608, "three workgroups per CU (160 KiB LDS)");
+    static_assert(LISTCAP < SPH_CNT_WALK && LISTCAP <= SPH_GLIST_ROWS, "gcnt is a byte; glist has SPH_GLIST_ROWS rows");
+    static_assert(bytes(true) <= 40960, "filtering sweeps: at least four workgroups per CU (160 KiB LDS)");
+    static_assert(bytes(false) <= 32768, "force sweep: five workgroups per CU");
 };
 
 template <int MODE, class CFG>
@@ -330,16 +332,18 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
                                                       int bricks_per_xcd, unsigned short* __restrict__ glist,
                                                       unsigned char* __restrict__ gcnt, int cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sX = reinterpret_cast<float*>(smem + CFG::OFF_X);
-    float* sY = reinterpret_cast<float*>(smem + CFG::OFF_Y);
-    float* sZ = reinterpret_cast<float*>(smem + CFG::OFF_Z);
-    float* sW = reinterpret_cast<float*>(smem + CFG::OFF_W);
-    int* sCE = reinterpret_cast<int*>(smem + CFG::OFF_CE);      // [NCOL][NZS] raw cell_end values of the shell
-    int* sColG = reinterpret_cast<int*>(smem + CFG::OFF_COLG);  // global start of the column segment
-    int* sColS = reinterpret_cast<int*>(smem + CFG::OFF_COLS);  // LDS start of the column segment (+ total at [64])
-    int* sTG = reinterpret_cast<int*>(smem + CFG::OFF_TG);      // global start of the column's targets
-    int* sTOff = reinterpret_cast<int*>(smem + CFG::OFF_TOFF);  // target-number start of the column (+ total at [64])
-    unsigned short* sList = reinterpret_cast<unsigned short*>(smem + CFG::OFF_LIST);  // absent when the list is read from HBM
+    constexpr bool HAS_W = !mode_reads_list<MODE>();
+    float4* sQ = reinterpret_cast<float4*>(smem + CFG::OFF_Q);
+    float* sW = reinterpret_cast<float*>(smem + CFG::off_w(HAS_W));  // only when HAS_W
+    // Shell origin.  Candidates are staged in shell-local coordinates as (-2x', -2y', -2z', |x'|^2) so the
+    // filter is |x_i - x_j|^2 - |x_i'|^2 = s_j + x_i'.(-2 x_j') : 3 FMA + 1 compare per candidate.  Local
+    // coordinates are <= 6 cells, so the cancellation error (~1e-8) is far below the 2e-4 h^2 filter margin,
+    // and x' = x - O is exact (Sterbenz) away from the first cells, so phase 2 recovers x_i - x_j unchanged.
+    int* sCE = reinterpret_cast<int*>(smem + CFG::off_ce(HAS_W));      // [NCOL][NZS] raw cell_end values of the shell
+    int* sColG = reinterpret_cast<int*>(smem + CFG::off_colg(HAS_W));  // global start of the column segment
+    int* sColS = reinterpret_cast<int*>(smem + CFG::off_cols(HAS_W));  // LDS start of the column segment (+ total at [64])
+    int* sTG = reinterpret_cast<int*>(smem + CFG::off_tg(HAS_W));      // global start of the column's targets
+    int* sTOff = reinterpret_cast<int*>(smem + CFG::off_toff(HAS_W));  // target-number start of the column (+ total at [64])
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -358,6 +362,8 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
     const int ncy = sy1 - sy0 + 1;
     const int ncols = (sx1 - sx0 + 1) * ncy;
     const int nzs = sz1 - sz0 + 1;
+    const float Ox = (float)(sx0 + d.ox) * d.grid_size, Oy = (float)(sy0 + d.oy) * d.grid_size,
+                Oz = (float)(sz0 + d.oz) * d.grid_size;
 
     // ---- step A: per shell column, the cell-end table and the segment scan (wave 0) ----
     if (wave == 0) {
@@ -407,7 +413,13 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
         for (int u = 0; u < CFG::PER; ++u) {
             const int idx = tid + u * TPB;
             if (idx < total) {
-                sX[idx] = buf[u].x; sY[idx] = buf[u].y; sZ[idx] = buf[u].z; sW[idx] = buf[u].w;
+                const float xl = buf[u].x - Ox, yl = buf[u].y - Oy, zl = buf[u].z - Oz;
+                if (HAS_W) {
+                    sQ[idx] = make_float4(-2.0f * xl, -2.0f * yl, -2.0f * zl, xl * xl + yl * yl + zl * zl);
+                    sW[idx] = buf[u].w;
+                } else {
+                    sQ[idx] = make_float4(-2.0f * xl, -2.0f * yl, -2.0f * zl, buf[u].w);
+                }
             }
         }
     }
@@ -433,96 +445,93 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
             const int cz = d.key[gi] % d.nz;
             const int klo = (cz > 0 ? cz - 1 : 0) - sz0;  // first cell of the z-run, shell-relative
             const int khi = (cz < d.nz - 1 ? cz + 1 : d.nz - 1) - sz0;
-            const float h2p = d.h * d.h * 1.000001f;  // superset filter; the exact r < h test is in phase 2
-            // point-to-cell distances for culling (exact: a culled cell cannot hold a particle within h;
-            // 0.1% slack on h^2 covers the ulp-level mismatch between float cell hashing and cell geometry)
-            const float h2c = d.h * d.h * 1.001f;
-            // offsets inside the own cell, clamped so that a particle hashed into a boundary cell from
-            // outside the domain only makes the culling more conservative
-            const float ux = fminf(fmaxf(t.x - (float)(ix + d.ox) * d.grid_size, 0.0f), d.grid_size),
-                        uy = fminf(fmaxf(t.y - (float)(iy + d.oy) * d.grid_size, 0.0f), d.grid_size),
-                        uz = fminf(fmaxf(t.z - (float)(cz + d.oz) * d.grid_size, 0.0f), d.grid_size);
-            const float gzlo = uz * uz, gzhi = (d.grid_size - uz) * (d.grid_size - uz);
-            char* lp = reinterpret_cast<char*>(sList) + tid * 2;
-            char* const lp0 = lp;
-            char* const lp_guard = lp + CFG::LISTCAP * TPB * 2;
+            const float txl_ = t.x - Ox, tyl_ = t.y - Oy, tzl_ = t.z - Oz;
+            // superset filter (exact r < h test in phase 2): r2 - |x_i'|^2 < h^2 (1 + 2e-4) - |x_i'|^2
+            const float thr = d.h * d.h * 1.0002f - (txl_ * txl_ + tyl_ * tyl_ + tzl_ * tzl_);
+            unsigned short* const gl = glist + gi;  // row k of this target's list: gl[k * cap]
             // phase 1: filter the 9 column runs into the private index list (4 LDS slots in flight)
             for (int dx = -1; dx <= 1; ++dx) {
                 const int nx = ix + dx;
                 if (nx < 0 || nx >= d.nx) continue;
-                const float gx = dx == 0 ? 0.0f : (dx > 0 ? d.grid_size - ux : ux);
                 for (int dy = -1; dy <= 1; ++dy) {
                     const int ny = iy + dy;
                     if (ny < 0 || ny >= d.ny) continue;
-                    const float gy = dy == 0 ? 0.0f : (dy > 0 ? d.grid_size - uy : uy);
-                    const float gxy2 = gx * gx + gy * gy;
-                    if (gxy2 > h2c) continue;  // whole column out of reach
                     const int ncol = (nx - sx0) * ncy + (ny - sy0);
                     const int rel = sColS[ncol] - sColG[ncol];
-                    // trim the lower / upper cell of the z-run when it is out of reach
-                    const int kl = klo + ((cz > 0 && gxy2 + gzlo > h2c) ? 1 : 0);
-                    const int kh = khi - ((cz < d.nz - 1 && gxy2 + gzhi > h2c) ? 1 : 0);
-                    const int lo = sCE[ncol * CFG::NZS + kl] + rel;
-                    const int hi = sCE[ncol * CFG::NZS + kh + 1] + rel;
+                    const int lo = sCE[ncol * CFG::NZS + klo] + rel;
+                    const int hi = sCE[ncol * CFG::NZS + khi + 1] + rel;
                     const unsigned tag = (unsigned)ncol << 11;
-#define SPH_FILTER(X_, Y_, Z_, jj)                                                   \
-    {                                                                                \
-        const float rx_ = t.x - (X_), ry_ = t.y - (Y_), rz_ = t.z - (Z_);            \
-        const float r2_ = rx_ * rx_ + ry_ * ry_ + rz_ * rz_;                         \
-        if (r2_ < h2p) {                                                             \
-            *reinterpret_cast<unsigned short*>(lp < lp_guard ? lp : lp_guard) =      \
-                (unsigned short)(tag | (unsigned)(jj));                              \
-            lp += TPB * 2;                                                           \
-        }                                                                            \
-    }
-                    int j = lo;
-                    for (; j + 4 <= hi; j += 4) {
-                        const float x0 = sX[j], x1 = sX[j + 1], x2 = sX[j + 2], x3 = sX[j + 3];
-                        const float y0 = sY[j], y1 = sY[j + 1], y2 = sY[j + 2], y3 = sY[j + 3];
-                        const float z0 = sZ[j], z1 = sZ[j + 1], z2 = sZ[j + 2], z3 = sZ[j + 3];
-                        SPH_FILTER(x0, y0, z0, j) SPH_FILTER(x1, y1, z1, j + 1) SPH_FILTER(x2, y2, z2, j + 2)
-                        SPH_FILTER(x3, y3, z3, j + 3)
+// Hits are collected in a per-run bitmask register (no LDS traffic while filtering) and turned into list
+// entries once per chunk of <= 32 candidates: ~7 ds_write per run instead of one per candidate.
+#define SPH_TEST(Q_) (fmaf(txl_, (Q_).x, fmaf(tyl_, (Q_).y, fmaf(tzl_, (Q_).z, (Q_).w))) < thr)
+                    for (int base = lo; base < hi; base += 32) {
+                        const int n = min(32, hi - base);
+                        unsigned mask = 0;
+                        int k = 0;
+                        for (; k + 8 <= n; k += 8) {
+                            const float4* q = &sQ[base + k];
+                            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                            const float4 q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7];
+                            const unsigned byte = (SPH_TEST(q0) ? 1u : 0u) | (SPH_TEST(q1) ? 2u : 0u) |
+                                                  (SPH_TEST(q2) ? 4u : 0u) | (SPH_TEST(q3) ? 8u : 0u) |
+                                                  (SPH_TEST(q4) ? 16u : 0u) | (SPH_TEST(q5) ? 32u : 0u) |
+                                                  (SPH_TEST(q6) ? 64u : 0u) | (SPH_TEST(q7) ? 128u : 0u);
+                            mask |= byte << k;
+                        }
+                        for (; k < n; ++k) {
+                            const float4 q0 = sQ[base + k];
+                            mask |= (SPH_TEST(q0) ? 1u : 0u) << k;
+                        }
+                        const unsigned tagbase = tag | (unsigned)base;
+                        while (mask) {  // rows coalesce across the wave's lanes (consecutive gi)
+                            const unsigned bit = (unsigned)__ffs((int)mask) - 1u;
+                            mask &= mask - 1u;
+                            if (cnt < CFG::LISTCAP) gl[(size_t)cnt * cap] = (unsigned short)(tagbase + bit);
+                            ++cnt;
+                            if (mode_inline_physics<MODE>()) {
+                                // the density pair term is cheap: do it here instead of re-reading the list
+                                const int j = base + (int)bit;
+                                const float4 q = sQ[j];
+                                const float rx = fmaf(0.5f, q.x, txl_), ry = fmaf(0.5f, q.y, tyl_), rz = fmaf(0.5f, q.z, tzl_);
+                                const float r2 = rx * rx + ry * ry + rz * rz;
+                                const float rinv = sph_rsq(r2);
+                                const float rn = r2 * rinv;
+                                if (rn < d.h && j != li)  // particle_system.py:385
+                                    pair_physics<MODE>(d, t, rx, ry, rz, r2, rn, rinv, make_float4(0.f, 0.f, 0.f, sW[j]),
+                                                       make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), 0);
+                            }
+                        }
                     }
-                    for (; j < hi; ++j) {
-                        const float x0 = sX[j], y0 = sY[j], z0 = sZ[j];
-                        SPH_FILTER(x0, y0, z0, j)
-                    }
-#undef SPH_FILTER
+#undef SPH_TEST
                 }
             }
-            cnt = (int)(lp - lp0) / (TPB * 2);
             if (cnt > CFG::LISTCAP && !(d.ablate & 8)) walk = true;  // list overflow (extreme compression): exact slow path
+            if (mode_writes_list<MODE>()) gcnt[gi] = (unsigned char)(walk ? SPH_CNT_WALK : cnt);
+            __threadfence_block();  // this lane re-reads its own entries below
         }
         if (mode_reads_list<MODE>() && g && !overflow) {
             cnt = gcnt[gi];
             if (cnt == SPH_CNT_WALK) { walk = true; cnt = 0; }
         }
-        if (mode_writes_list<MODE>() && g) {
-            gcnt[gi] = (unsigned char)(walk ? SPH_CNT_WALK : cnt);
-            if (!walk && !(d.ablate & 2))
-                for (int k = 0; k < cnt; ++k) glist[(size_t)k * cap + gi] = sList[k * TPB + tid];
-        }
-        if (g && !walk && !(d.ablate & 1)) {
+        if (mode_writes_list<MODE>() && g && overflow) gcnt[gi] = (unsigned char)SPH_CNT_WALK;
+        if (g && !walk && !(d.ablate & 1) && !mode_inline_physics<MODE>()) {
             // phase 2: pair physics over the list; the next entry's records are prefetched
             unsigned e1 = 0, e2 = 0;  // entries k+1 and k+2
-            if (mode_reads_list<MODE>()) {
-                if (cnt > 0) e1 = glist[gi];
-                if (cnt > 1) e2 = glist[(size_t)cap + gi];
-            } else {
-                if (cnt > 0) e1 = sList[tid];
-                if (cnt > 1) e2 = sList[TPB + tid];
-            }
+            if (cnt > 0) e1 = glist[gi];
+            if (cnt > 1) e2 = glist[(size_t)cap + gi];
             float4 An = make_float4(0.f, 0.f, 0.f, 0.f);
             float4 Bn = make_float4(0.f, 0.f, 0.f, 0.f), Cn = Bn;
             int gn = 0, jn = -1;
             if (cnt > 0) {
                 jn = e1 & 2047;
                 const int c2 = e1 >> 11;
-                An = make_float4(sX[jn], sY[jn], sZ[jn], sW[jn]);
+                An = sQ[jn];  // (-2x', -2y', -2z', m_V)
+                if (HAS_W) An.w = sW[jn];
                 gn = sColG[c2] + (jn - sColS[c2]);
                 if (mode_needs_B<MODE>()) Bn = d.vf[gn];
                 if (mode_needs_C<MODE>()) Cn = load_C_global<MODE>(d, gn);
             }
+            const float txl = t.x - Ox, tyl = t.y - Oy, tzl = t.z - Oz;
             for (int k = 0; k < cnt; ++k) {
                 const float4 A = An;
                 const float4 B = Bn, Cc = Cn;
@@ -530,15 +539,15 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
                 if (k + 1 < cnt) {
                     jn = e2 & 2047;
                     const int c2 = e2 >> 11;
-                    An = make_float4(sX[jn], sY[jn], sZ[jn], sW[jn]);
+                    An = sQ[jn];
+                    if (HAS_W) An.w = sW[jn];
                     gn = sColG[c2] + (jn - sColS[c2]);
                     if (mode_needs_B<MODE>()) Bn = d.vf[gn];
                     if (mode_needs_C<MODE>()) Cn = load_C_global<MODE>(d, gn);
-                    if (k + 2 < cnt)
-                        e2 = mode_reads_list<MODE>() ? (unsigned)glist[(size_t)(k + 2) * cap + gi]
-                                                     : (unsigned)sList[(k + 2) * TPB + tid];
+                    if (k + 2 < cnt) e2 = glist[(size_t)(k + 2) * cap + gi];
                 }
-                const float rx = t.x - A.x, ry = t.y - A.y, rz = t.z - A.z;
+                // x_i' - x_j' with x_j' = -A/2 (exact): the same difference as x_i - x_j
+                const float rx = fmaf(0.5f, A.x, txl), ry = fmaf(0.5f, A.y, tyl), rz = fmaf(0.5f, A.z, tzl);
                 const float r2 = rx * rx + ry * ry + rz * rz;
                 const float rinv = sph_rsq(r2);
                 const float rn = r2 * rinv;
@@ -568,10 +577,10 @@ __global__ __launch_bounds__(TPB) void k_eos(DevView d) {
 // ---------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------
-typedef BrickCfg<4, 2, 4, 1664, 47> Cfg0;  // 4x2x4 cells: 1152 candidates / 256 targets at rest
-typedef BrickCfg<2, 2, 8, 1664, 47> Cfg1;  // 2x2x8 cells: 1280 candidates / 256 targets at rest
-typedef BrickCfg<2, 4, 4, 1664, 47> Cfg2;  // 2x4x4 cells
-typedef BrickCfg<2, 2, 4, 1664, 47> Cfg3;  // 2x2x4 cells:  768 candidates / 128 targets at rest
+typedef BrickCfg<4, 2, 4, 1792, 63> Cfg0;  // 4x2x4 cells: 1152 candidates / 256 targets at rest
+typedef BrickCfg<2, 2, 8, 1792, 63> Cfg1;  // 2x2x8 cells: 1280 candidates / 256 targets at rest
+typedef BrickCfg<2, 4, 4, 1792, 63> Cfg2;  // 2x4x4 cells
+typedef BrickCfg<2, 2, 4, 1792, 63> Cfg3;  // 2x2x4 cells:  768 candidates / 128 targets at rest
 
 template <int MODE>
 static int launch_simple(SphContext* c, const int* list, int n) {
@@ -589,7 +598,7 @@ static int launch_brick_cfg(SphContext* c) {
               nbz = (d.nz + CFG::BZ - 1) / CFG::BZ;
     const int nbricks = nbx * nby * nbz;
     const int per_xcd = (nbricks + 7) / 8;
-    const int bytes = mode_reads_list<MODE>() ? CFG::BYTES_NOLIST : CFG::BYTES_LIST;
+    const int bytes = CFG::bytes(!mode_reads_list<MODE>());
     static bool attr_set = false;
     if (!attr_set) {
         SPH_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gather_brick<MODE, CFG>),

@@ -23,7 +23,7 @@
 #define SPH_MATERIAL_SOLID 0  // particle_system.py:30
 #define SPH_MATERIAL_FLUID 1  // particle_system.py:31
 #define SPH_MAX_TIMED_STEPS 128
-#define SPH_GLIST_ROWS 48
+#define SPH_GLIST_ROWS 64
 
 struct DevView {
     int N, G;

@@ -65,8 +65,16 @@ __device__ __forceinline__ float4 make_C_from_aux(const float4 aux) {
     return c;
 }
 
+// E = the target's own aux (stand-alone force modes) or eos (fused force) record, loaded by the caller
 template <int MODE>
-__device__ __forceinline__ void target_init(const DevView& d, Target& t, int i, const float4 A, const float4 B) {
+__device__ __forceinline__ float4 target_load_E(const DevView& d, int i) {
+    if (MODE == GM_NONPRESSURE || MODE == GM_PRESSURE) return d.aux[i];
+    if (MODE == GM_FORCE_FUSED) return d.eos[i];
+    return make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <int MODE>
+__device__ __forceinline__ void target_init(const DevView& d, Target& t, const float4 A, const float4 B, const float4 E) {
     t.x = A.x; t.y = A.y; t.z = A.z; t.mV = A.w;
     t.vx = B.x; t.vy = B.y; t.vz = B.z;
     t.flags = __float_as_int(B.w);
@@ -75,17 +83,15 @@ __device__ __forceinline__ void target_init(const DevView& d, Target& t, int i, 
     t.px = t.py = t.pz = 0.0f;
     t.m = t.rho = t.p = t.dpi = t.st_c = t.dpj_solid = 0.0f;
     if (MODE == GM_NONPRESSURE || MODE == GM_PRESSURE) {
-        const float4 aux = d.aux[i];
-        t.m = aux.x; t.rho = aux.y; t.p = aux.z;
-        t.dpi = aux.z / (aux.y * aux.y);  // WCSPH.py:49
-        t.st_c = d.sigma / aux.x;         // WCSPH.py:100
-        t.dpj_solid = aux.z / (d.rho0 * d.rho0);
+        t.m = E.x; t.rho = E.y; t.p = E.z;
+        t.dpi = E.z / (E.y * E.y);  // WCSPH.py:49
+        t.st_c = d.sigma / E.x;     // WCSPH.py:100
+        t.dpj_solid = E.z / (d.rho0 * d.rho0);
     }
     if (MODE == GM_FORCE_FUSED) {
-        const float4 e = d.eos[i];
-        t.dpi = e.x; t.m = e.z; t.rho = e.w;
-        t.p = e.x * (e.w * e.w);
-        t.st_c = d.sigma / e.z;
+        t.dpi = E.x; t.m = E.z; t.rho = E.w;
+        t.p = E.x * (E.w * E.w);
+        t.st_c = d.sigma / E.z;
         t.dpj_solid = t.p / (d.rho0 * d.rho0);
     }
     if (MODE == GM_BVOL_STATIC || MODE == GM_BVOL_DYNAMIC) t.s0 = d.w_zero;  // sph_base.py:95, 110
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(TPB) void k_gather_simple(DevView d, const int* __r
     Target t;
     const float4 A = d.xm[i];
     const float4 B = d.vf[i];
-    target_init<MODE>(d, t, i, A, B);
+    target_init<MODE>(d, t, A, B, target_load_E<MODE>(d, i));
     const bool g = target_gathers<MODE>(t.flags);
     if (g) gather_walk_global<MODE>(d, t, i);
     target_finish<MODE>(d, t, i, g);
@@ -397,6 +403,21 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
     if (T == 0) return;
     const bool overflow = total > CFG::CAP;
 
+    // round-0 target loads are issued here, together with the staging loads below, so that their latency is
+    // not a third dependent phase after the staging barrier
+    int col_0 = 0, gi_0 = 0, key_0 = 0;
+    float4 Ai_0 = make_float4(0.f, 0.f, 0.f, 0.f), Bi_0 = Ai_0, Ei_0 = Ai_0;
+    if (tid < T) {
+#pragma unroll
+        for (int step = 16; step > 0; step >>= 1)
+            if (sTOff[col_0 + step] <= tid) col_0 += step;
+        gi_0 = sTG[col_0] + (tid - sTOff[col_0]);
+        Ai_0 = d.xm[gi_0];
+        Bi_0 = d.vf[gi_0];
+        Ei_0 = target_load_E<MODE>(d, gi_0);
+        key_0 = d.key[gi_0];
+    }
+
     // ---- step B: stage the shell's (x, y, z, m_V) records; all loads of a lane in flight together ----
     if (!overflow) {
         float4 buf[CFG::PER];
@@ -427,22 +448,28 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
 
     // ---- step C: targets ----
     for (int tn = tid; tn < T; tn += TPB) {
-        int col = 0;
+        int col = col_0, gi = gi_0, key_i = key_0;
+        float4 Ai = Ai_0, Bi = Bi_0, Ei = Ei_0;
+        if (tn != tid) {  // later rounds (bricks with more than 256 targets)
+            col = 0;
 #pragma unroll
-        for (int step = 16; step > 0; step >>= 1)
-            if (sTOff[col + step] <= tn) col += step;
-        const int gi = sTG[col] + (tn - sTOff[col]);
+            for (int step = 16; step > 0; step >>= 1)
+                if (sTOff[col + step] <= tn) col += step;
+            gi = sTG[col] + (tn - sTOff[col]);
+            Ai = d.xm[gi];
+            Bi = d.vf[gi];
+            Ei = target_load_E<MODE>(d, gi);
+            key_i = d.key[gi];
+        }
         Target t;
-        const float4 Ai = d.xm[gi];
-        const float4 Bi = d.vf[gi];
-        target_init<MODE>(d, t, gi, Ai, Bi);
+        target_init<MODE>(d, t, Ai, Bi, Ei);
         const bool g = target_gathers<MODE>(t.flags);
         bool walk = g && overflow;
         int cnt = 0;
         const int li = sColS[col] + (gi - sColG[col]);  // own LDS slot
         if (g && !overflow && !mode_reads_list<MODE>() && !(d.ablate & 4)) {
             const int ix = sx0 + col / ncy, iy = sy0 + col % ncy;
-            const int cz = d.key[gi] % d.nz;
+            const int cz = key_i - sph_flatten(d, ix, iy, 0);  // key = flatten(ix, iy, cz)
             const int klo = (cz > 0 ? cz - 1 : 0) - sz0;  // first cell of the z-run, shell-relative
             const int khi = (cz < d.nz - 1 ? cz + 1 : d.nz - 1) - sz0;
             const float txl_ = t.x - Ox, tyl_ = t.y - Oy, tzl_ = t.z - Oz;
@@ -556,7 +583,7 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
             }
         }
         if (walk) {
-            target_init<MODE>(d, t, gi, Ai, Bi);
+            target_init<MODE>(d, t, Ai, Bi, Ei);
             gather_walk_global<MODE>(d, t, gi);
         }
         target_finish<MODE>(d, t, gi, g);

@@ -191,6 +191,10 @@ int32_t sph_truncate(SphContext* ctx, int32_t n);
 int32_t sph_pack_range(SphContext* ctx, int32_t first, int32_t count, void* device_dst);
 /* Append `count` packed records after the current particles (count += n). */
 int32_t sph_append_records(SphContext* ctx, const void* device_src, int32_t count);
+/* Restrict the TARGETS of the density (+EOS) and force sweeps to local x layers [lo, hi) (candidates are never
+ * restricted).  A slab rank sets density = owned + first ghost layer, force = owned: the outer ghost layer only
+ * serves as neighbours.  Default: all layers. */
+int32_t sph_set_target_layers(SphContext* ctx, int32_t density_lo, int32_t density_hi, int32_t force_lo, int32_t force_hi);
 /* The sort of sph_step (no acceleration permutation): hash + scan + scatter. */
 int32_t sph_sort(SphContext* ctx);
 /* One step's sweeps without the sort: boundary volume, density+EOS, force, advect +

@@ -80,6 +80,7 @@ SYMBOLS = [
     ("sph_truncate", C.c_int32, [_ctx, C.c_int32]),
     ("sph_pack_range", C.c_int32, [_ctx, C.c_int32, C.c_int32, C.c_void_p]),
     ("sph_append_records", C.c_int32, [_ctx, C.c_void_p, C.c_int32]),
+    ("sph_set_target_layers", C.c_int32, [_ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     ("sph_sort", C.c_int32, [_ctx]),
     ("sph_sweeps", C.c_int32, [_ctx]),
 ]

@@ -21,6 +21,7 @@ DevView sph_view(const SphContext* c) {
     const SphParams& p = c->p;
     d.N = c->N; d.G = c->G;
     d.nx = p.grid_num[0]; d.ny = p.grid_num[1]; d.nz = p.grid_num[2];
+    d.tgt_lo = 0; d.tgt_hi = p.grid_num[0];
     d.ablate = c->opt_ablate;
     d.drop_outside = c->opt_drop_outside;
     d.ox = p.cell_origin[0]; d.oy = p.cell_origin[1]; d.oz = p.cell_origin[2];
@@ -92,6 +93,8 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     c->N = params->n_particles;
     c->cap = params->capacity > 0 ? params->capacity : 1;
     c->G = params->grid_num[0] * params->grid_num[1] * params->grid_num[2];
+    c->tgt_layers[0] = c->tgt_layers[2] = 0;
+    c->tgt_layers[1] = c->tgt_layers[3] = params->grid_num[0];
     c->opt_gather_impl = 1;
     c->opt_fused = 1;
     c->opt_timing = 0;
@@ -455,6 +458,14 @@ static int step_sweeps(SphContext* c, hipEvent_t* ev, const int32_t* dynamic_ids
             rc = rc ? rc : sphk_enforce_boundary(c, SPH_MATERIAL_SOLID);
             if (rc) return rc;
         }
+    return 0;
+}
+
+int32_t sph_set_target_layers(SphContext* c, int32_t dlo, int32_t dhi, int32_t flo, int32_t fhi) {
+    if (!c) return SPH_E_INVALID;
+    const int nx = c->p.grid_num[0];
+    if (dlo < 0 || dhi > nx || dlo > dhi || flo < 0 || fhi > nx || flo > fhi) return sph_fail(c, SPH_E_INVALID, "sph_set_target_layers: bad range");
+    c->tgt_layers[0] = dlo; c->tgt_layers[1] = dhi; c->tgt_layers[2] = flo; c->tgt_layers[3] = fhi;
     return 0;
 }
 

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
             for (int k = 1; k < CFG::NZS; ++k)
                 if (k <= nzs) sCE[lane * CFG::NZS + k] = d.cell_end[base + k - 1];
             len = sCE[lane * CFG::NZS + nzs] - gstart;
-            if (ix >= cx0 && ix < cx1 && iy >= cy0 && iy < cy1) {
+            if (ix >= cx0 && ix < cx1 && iy >= cy0 && iy < cy1 && ix >= d.tgt_lo && ix < d.tgt_hi) {
                 // targets: cells cz0 .. cz1-1 of this column (true start, also for flat cell 0)
                 tstart = (base + (cz0 - sz0) > 0) ? sCE[lane * CFG::NZS + (cz0 - sz0)] : 0;
                 tlen = sCE[lane * CFG::NZS + (cz1 - sz0)] - tstart;
@@ -621,6 +621,8 @@ static int launch_simple(SphContext* c, const int* list, int n) {
 template <int MODE, class CFG>
 static int launch_brick_cfg(SphContext* c) {
     DevView d = sph_view(c);
+    if (MODE == GM_DENSITY_EOS) { d.tgt_lo = c->tgt_layers[0]; d.tgt_hi = c->tgt_layers[1]; }
+    if (MODE == GM_FORCE_FUSED) { d.tgt_lo = c->tgt_layers[2]; d.tgt_hi = c->tgt_layers[3]; }
     const int nbx = (d.nx + CFG::BX - 1) / CFG::BX, nby = (d.ny + CFG::BY - 1) / CFG::BY,
               nbz = (d.nz + CFG::BZ - 1) / CFG::BZ;
     const int nbricks = nbx * nby * nbz;

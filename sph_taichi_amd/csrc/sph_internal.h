@@ -29,6 +29,7 @@ struct DevView {
     int N, G;
     int nx, ny, nz;
     int ox, oy, oz;  // cell_origin (multi-GPU slabs)
+    int tgt_lo, tgt_hi;  // local x layers whose particles are targets of this sweep
     int drop_outside;  // slab mode: x layer outside the local grid -> virtual cell G
     int ablate;      // debug: bit0 skip phase 2, bit1 skip list write-out, bit2 skip phase 1 (profiling only)
     float grid_size, h, inv_h, d, d2, m_V0, rho0, stiffness, exponent, sigma, dt;
@@ -57,6 +58,7 @@ struct SphContext {
     int cold_cap;  // rows of x0_cold / color_cold
     int G;
     int cur;  // which ping-pong set is current
+    int tgt_layers[4];  // density lo/hi, force lo/hi (slab mode); default 0..nx
     int in_off;  // first live record of the current set (non-zero only between sph_select_range and the next sort)
     float4* xm[2];
     float4* vf[2];

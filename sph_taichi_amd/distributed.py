@@ -173,6 +173,12 @@ class SlabSolver:
         dyn_blocks = [b for b in cfg.get_rigid_blocks() if b.get("isDynamic")]
         self.ps.set_option(_lib.OPT_NO_DYNAMIC_SOLIDS, 0 if dyn_blocks else 1)
         self.ps.set_option(_lib.OPT_SLAB_DROP_OUTSIDE, 1)
+        nxl = self.x_hi - self.x_lo + 2 * HALO
+        # targets: density on owned + ghost layer 1 (its rho/p feed the owned forces); forces on owned only,
+        # or also on ghost layer 1 when dynamic solids exist (their owner accumulates the coupling reaction
+        # from its ghost fluid neighbours)
+        f_lo, f_hi = (HALO - 1, nxl - HALO + 1) if dyn_blocks else (HALO, nxl - HALO)
+        self.ps._call("sph_set_target_layers", HALO - 1, nxl - HALO + 1, f_lo, f_hi)
         self.solver = self.ps.build_solver()
         self.nx_local = self.x_hi - self.x_lo + 2 * HALO
         self.capacity = capacity

@@ -182,6 +182,10 @@ int32_t sph_get_particle_count(SphContext* ctx, int32_t* n);
 /* out[k] = number of particles in local x-layers < layers[k] (valid after
  * sph_prefix_sum / the sort).  Synchronises. */
 int32_t sph_layer_offsets(SphContext* ctx, const int32_t* layers, int32_t n, int32_t* out);
+/* Split form: _begin enqueues the copies (pinned host memory + an event) right behind the sort and returns;
+ * _end waits for that event only, so kernels enqueued in between (sph_sweeps) keep the GPU busy. n <= 16. */
+int32_t sph_layer_offsets_begin(SphContext* ctx, const int32_t* layers, int32_t n);
+int32_t sph_layer_offsets_end(SphContext* ctx, int32_t* out, int32_t n);
 /* Keep only [first, first+count) of the current order as the particle set (drops
  * ghosts); must be followed by a sort before any sweep. */
 int32_t sph_select_range(SphContext* ctx, int32_t first, int32_t count);

@@ -76,6 +76,8 @@ SYMBOLS = [
     ("sph_reset_timings", C.c_int32, [_ctx]),
     ("sph_get_particle_count", C.c_int32, [_ctx, C.POINTER(C.c_int32)]),
     ("sph_layer_offsets", C.c_int32, [_ctx, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]),
+    ("sph_layer_offsets_begin", C.c_int32, [_ctx, C.POINTER(C.c_int32), C.c_int32]),
+    ("sph_layer_offsets_end", C.c_int32, [_ctx, C.POINTER(C.c_int32), C.c_int32]),
     ("sph_select_range", C.c_int32, [_ctx, C.c_int32, C.c_int32]),
     ("sph_truncate", C.c_int32, [_ctx, C.c_int32]),
     ("sph_pack_range", C.c_int32, [_ctx, C.c_int32, C.c_int32, C.c_void_p]),

@@ -137,6 +137,8 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     rc = rc ? rc : alloc_dev(c, (void**)&c->rigid_R, 16 * sizeof(float));
     c->stage_bytes = cap * 16 > (size_t)c->G * 4 ? cap * 16 : (size_t)c->G * 4;
     rc = rc ? rc : alloc_dev(c, &c->stage, c->stage_bytes);
+    if (!rc && hipHostMalloc((void**)&c->h_pinned, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess) rc = SPH_E_NOMEM;
+    if (!rc && hipEventCreateWithFlags(&c->ev_off, hipEventDisableTiming) != hipSuccess) rc = SPH_E_NOMEM;
     if (!rc) rc = sphk_init_pid(c);
     for (int s = 0; s < SPH_MAX_TIMED_STEPS && !rc; ++s)
         for (int k = 0; k < 5 && !rc; ++k)
@@ -162,6 +164,8 @@ int32_t sph_destroy(SphContext* c) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < SPH_MAX_TIMED_STEPS; ++s)
         for (int k = 0; k < 5; ++k) if (c->ev[s][k]) (void)hipEventDestroy(c->ev[s][k]);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->ev_off) (void)hipEventDestroy(c->ev_off);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -529,6 +533,30 @@ int32_t sph_layer_offsets(SphContext* c, const int32_t* layers, int32_t n, int32
         else SPH_HIP(c, hipMemcpyAsync(&out[k], c->cell_end + (size_t)L * per_layer - 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     }
     SPH_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int32_t sph_layer_offsets_begin(SphContext* c, const int32_t* layers, int32_t n) {
+    ENTER(c);
+    if (!layers || n < 0 || n > 16) return SPH_E_INVALID;
+    if (!c->have_prefix) return sph_fail(c, SPH_E_STATE, "sph_layer_offsets_begin needs the prefix sum");
+    const int per_layer = c->p.grid_num[1] * c->p.grid_num[2];
+    c->off_zero_mask = 0;
+    for (int k = 0; k < n; ++k) {
+        const int L = layers[k];
+        if (L < 0 || L > c->p.grid_num[0]) return sph_fail(c, SPH_E_INVALID, "layer out of range");
+        if (L == 0) { c->off_zero_mask |= 1 << k; continue; }
+        SPH_HIP(c, hipMemcpyAsync(&c->h_pinned[k], c->cell_end + (size_t)L * per_layer - 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    }
+    SPH_HIP(c, hipEventRecord(c->ev_off, c->stream));
+    return 0;
+}
+
+int32_t sph_layer_offsets_end(SphContext* c, int32_t* out, int32_t n) {
+    ENTER(c);
+    if (!out || n < 0 || n > 16) return SPH_E_INVALID;
+    SPH_HIP(c, hipEventSynchronize(c->ev_off));
+    for (int k = 0; k < n; ++k) out[k] = (c->off_zero_mask >> k) & 1 ? 0 : c->h_pinned[k];
     return 0;
 }
 

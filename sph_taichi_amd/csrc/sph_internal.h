@@ -58,6 +58,9 @@ struct SphContext {
     int cold_cap;  // rows of x0_cold / color_cold
     int G;
     int cur;  // which ping-pong set is current
+    int* h_pinned;       // 16 ints of pinned host memory for sph_layer_offsets_begin/_end
+    hipEvent_t ev_off;   // recorded behind those copies
+    int off_zero_mask;   // which of the pending offsets are layer 0 (no copy needed)
     int tgt_layers[4];  // density lo/hi, force lo/hi (slab mode); default 0..nx
     int in_off;  // first live record of the current set (non-zero only between sph_select_range and the next sort)
     float4* xm[2];

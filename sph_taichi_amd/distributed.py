@@ -239,15 +239,27 @@ class SlabSolver:
                 ps._call("sph_append_records", C.c_void_p(buf.data_ptr()), n)
         self.stats["received"] += n_left + n_right
         ps._call("sph_sort")
-        self._after_sort()
-        if announce:                  # the next exchange's sizes are known now: tell the neighbours early
-            self.transport.start_counts(*self.next_counts())
+        # read the layer offsets back behind the sort, but enqueue the sweeps before waiting for them:
+        # the GPU runs the sweeps while the host picks up the numbers (strays in the virtual cell are
+        # still in the particle count during the sweeps; no brick ever visits them)
+        self._after_sort(begin_only=True)
         if sweeps:
             ps._call("sph_sweeps")
+        self._after_sort(end_only=True)
+        if announce:                  # the next exchange's sizes are known now: tell the neighbours early
+            self.transport.start_counts(*self.next_counts())
 
-    def _after_sort(self):
+    def _after_sort(self, begin_only=False, end_only=False):
         nx = self.nx_local
-        o = self._offsets([HALO, 2 * HALO + 1, nx - 2 * HALO - 1, nx - HALO, nx])
+        layers = [HALO, 2 * HALO + 1, nx - 2 * HALO - 1, nx - HALO, nx]
+        if not end_only:
+            arr = (C.c_int32 * len(layers))(*layers)
+            self.ps._call("sph_layer_offsets_begin", arr, len(layers))
+            if begin_only:
+                return
+        out = (C.c_int32 * len(layers))()
+        self.ps._call("sph_layer_offsets_end", out, len(layers))
+        o = list(out)
         self.ps._call("sph_truncate", o[4])               # drop the virtual cell
         self.off = o[:4]
         self.owned_range = (o[0], o[3] - o[0])

@@ -199,6 +199,25 @@ int32_t sph_append_records(SphContext* ctx, const void* device_src, int32_t coun
  * restricted).  A slab rank sets density = owned + first ghost layer, force = owned: the outer ghost layer only
  * serves as neighbours.  Default: all layers. */
 int32_t sph_set_target_layers(SphContext* ctx, int32_t density_lo, int32_t density_hi, int32_t force_lo, int32_t force_hi);
+/* One slab step's device work in two calls (same effect as the individual calls, fewer host round trips):
+ *   sph_slab_pack : pack [firstL, firstL+nL) into dstL and [firstR, ...) into dstR, then synchronise (the
+ *                   buffers are handed to the transport next);
+ *   sph_slab_advance : select [keep_first, keep_first+keep_count), append the two received ranges, sort,
+ *                   enqueue the offset read-back for `layers` (sph_layer_offsets_begin), enqueue the sweeps
+ *                   (if do_sweeps).  Follow with sph_layer_offsets_end + sph_truncate. */
+int32_t sph_slab_pack(SphContext* ctx, int32_t firstL, int32_t nL, void* dstL, int32_t firstR, int32_t nR, void* dstR);
+int32_t sph_slab_advance(SphContext* ctx, int32_t keep_first, int32_t keep_count, const void* srcL, int32_t nL,
+                         const void* srcR, int32_t nR, const int32_t* layers, int32_t n_layers, int32_t do_sweeps);
+/* Exchange hidden behind compute.  sph_slab_advance(..., do_sweeps = 2) runs only the boundary-volume and density
+ * sweeps after the sort.  sph_slab_forces then enqueues: force sweep of the boundary layers [bl_lo,bl_hi) and
+ * [br_lo,br_hi); the two halo packers (records [firstL,+nL) / [firstR,+nR) advanced by this step's Euler + wall
+ * update, written to dstL / dstR, arrays untouched); an event; the force sweep of the remaining owned layers; the
+ * in-place advect.  sph_slab_wait_pack blocks until the packers are done -- the caller starts the exchange while
+ * the interior force sweep is still running. */
+int32_t sph_slab_forces(SphContext* ctx, int32_t bl_lo, int32_t bl_hi, int32_t br_lo, int32_t br_hi,
+                        int32_t firstL, int32_t nL, void* dstL, int32_t firstR, int32_t nR, void* dstR);
+int32_t sph_slab_wait_pack(SphContext* ctx);
+int32_t sph_slab_density(SphContext* ctx);   /* moving boundary volume + density/EOS sweep (what do_sweeps = 2 runs) */
 /* The sort of sph_step (no acceleration permutation): hash + scan + scatter. */
 int32_t sph_sort(SphContext* ctx);
 /* One step's sweeps without the sort: boundary volume, density+EOS, force, advect +

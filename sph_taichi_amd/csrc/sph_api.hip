@@ -21,7 +21,7 @@ DevView sph_view(const SphContext* c) {
     const SphParams& p = c->p;
     d.N = c->N; d.G = c->G;
     d.nx = p.grid_num[0]; d.ny = p.grid_num[1]; d.nz = p.grid_num[2];
-    d.tgt_lo = 0; d.tgt_hi = p.grid_num[0];
+    d.tgt_lo = 0; d.tgt_hi = p.grid_num[0]; d.tgt_lo2 = d.tgt_hi2 = 0;
     d.ablate = c->opt_ablate;
     d.drop_outside = c->opt_drop_outside;
     d.ox = p.cell_origin[0]; d.oy = p.cell_origin[1]; d.oz = p.cell_origin[2];
@@ -139,6 +139,7 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     rc = rc ? rc : alloc_dev(c, &c->stage, c->stage_bytes);
     if (!rc && hipHostMalloc((void**)&c->h_pinned, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess) rc = SPH_E_NOMEM;
     if (!rc && hipEventCreateWithFlags(&c->ev_off, hipEventDisableTiming) != hipSuccess) rc = SPH_E_NOMEM;
+    if (!rc && hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) != hipSuccess) rc = SPH_E_NOMEM;
     if (!rc) rc = sphk_init_pid(c);
     for (int s = 0; s < SPH_MAX_TIMED_STEPS && !rc; ++s)
         for (int k = 0; k < 5 && !rc; ++k)
@@ -166,6 +167,7 @@ int32_t sph_destroy(SphContext* c) {
         for (int k = 0; k < 5; ++k) if (c->ev[s][k]) (void)hipEventDestroy(c->ev[s][k]);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->ev_off) (void)hipEventDestroy(c->ev_off);
+    if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -624,6 +626,72 @@ int32_t sph_reset_timings(SphContext* c) {
     int rc = harvest_events(c);
     if (rc) return rc;
     memset(&c->tm, 0, sizeof(c->tm));
+    return 0;
+}
+
+int32_t sph_slab_pack(SphContext* c, int32_t firstL, int32_t nL, void* dstL, int32_t firstR, int32_t nR, void* dstR) {
+    ENTER(c);
+    int rc = sph_pack_range(c, firstL, nL, dstL);
+    rc = rc ? rc : sph_pack_range(c, firstR, nR, dstR);
+    if (rc) return rc;
+    SPH_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int32_t sph_slab_advance(SphContext* c, int32_t keep_first, int32_t keep_count, const void* srcL, int32_t nL,
+                         const void* srcR, int32_t nR, const int32_t* layers, int32_t n_layers, int32_t do_sweeps) {
+    ENTER(c);
+    int rc = sph_select_range(c, keep_first, keep_count);
+    rc = rc ? rc : sph_append_records(c, srcL, nL);
+    rc = rc ? rc : sph_append_records(c, srcR, nR);
+    rc = rc ? rc : sph_sort(c);
+    rc = rc ? rc : sph_layer_offsets_begin(c, layers, n_layers);
+    if (!rc && do_sweeps == 1) rc = sph_sweeps(c);
+    if (!rc && do_sweeps == 2) {  // boundary volume + density only; sph_slab_forces does the rest
+        rc = refresh_dyn(c);
+        if (!rc && c->n_dyn_host > 0) rc = sphk_gather(c, GM_BVOL_DYNAMIC);
+        rc = rc ? rc : sphk_gather(c, GM_DENSITY_EOS);
+    }
+    return rc;
+}
+
+int32_t sph_slab_forces(SphContext* c, int32_t bl_lo, int32_t bl_hi, int32_t br_lo, int32_t br_hi,
+                        int32_t firstL, int32_t nL, void* dstL, int32_t firstR, int32_t nR, void* dstR) {
+    ENTER(c);
+    int rc = need_sorted(c, "sph_slab_forces");
+    if (rc) return rc;
+    if (!c->opt_fused || c->opt_gather_impl != 1) return sph_fail(c, SPH_E_STATE, "sph_slab_forces needs the fused brick sweeps");
+    if (firstL < 0 || nL < 0 || firstL + nL > c->N || firstR < 0 || nR < 0 || firstR + nR > c->N ||
+        (nL > 0 && !dstL) || (nR > 0 && !dstR))
+        return sph_fail(c, SPH_E_INVALID, "sph_slab_forces: bad pack range");
+    const int f_lo = c->tgt_layers[2], f_hi = c->tgt_layers[3];
+    // clip the boundary sets to the force-target layers and keep them disjoint
+    bl_lo = bl_lo < f_lo ? f_lo : bl_lo; bl_hi = bl_hi > f_hi ? f_hi : bl_hi;
+    br_hi = br_hi > f_hi ? f_hi : br_hi; br_lo = br_lo < bl_hi ? bl_hi : br_lo;
+    if (bl_hi < bl_lo) bl_hi = bl_lo;
+    if (br_lo > br_hi) br_lo = br_hi;
+    // boundary sets (incl. the ghost-side strips that exist when dynamic solids are force targets): ONE launch
+    rc = sphk_gather_layers(c, GM_FORCE_FUSED, f_lo, bl_hi, br_lo, f_hi);
+    rc = rc ? rc : sphk_pack_advected(c, firstL, nL, dstL);
+    rc = rc ? rc : sphk_pack_advected(c, firstR, nR, dstR);
+    if (rc) return rc;
+    SPH_HIP(c, hipEventRecord(c->ev_pack, c->stream));
+    rc = sphk_gather_layers(c, GM_FORCE_FUSED, bl_hi, br_lo, 0, 0);  // interior: overlaps with the exchange
+    rc = rc ? rc : sphk_advect(c, true);
+    return rc;
+}
+
+int32_t sph_slab_density(SphContext* c) {
+    ENTER(c);
+    int rc = need_sorted(c, "sph_slab_density");
+    rc = rc ? rc : refresh_dyn(c);
+    if (!rc && c->n_dyn_host > 0) rc = sphk_gather(c, GM_BVOL_DYNAMIC);
+    return rc ? rc : sphk_gather(c, GM_DENSITY_EOS);
+}
+
+int32_t sph_slab_wait_pack(SphContext* c) {
+    ENTER(c);
+    SPH_HIP(c, hipEventSynchronize(c->ev_pack));
     return 0;
 }
 

@@ -334,8 +334,9 @@ struct BrickCfg {
 };
 
 template <int MODE, class CFG>
-__global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nby, int nbz, int nbricks,
-                                                      int bricks_per_xcd, unsigned short* __restrict__ glist,
+__global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int bx0, int nbx0, int bx1, int nby, int nbz,
+                                                      int nbricks, int bricks_per_xcd,
+                                                      unsigned short* __restrict__ glist,
                                                       unsigned char* __restrict__ gcnt, int cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool HAS_W = !mode_reads_list<MODE>();
@@ -358,9 +359,11 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
     const int b = blockIdx.x;
     const int brick = (b & 7) * bricks_per_xcd + (b >> 3);
     if (brick >= nbricks) return;
+    // the launch enumerates two groups of brick columns in x: [bx0, bx0+nbx0) then [bx1, ...)
     const int bzi = brick % nbz;
     const int byi = (brick / nbz) % nby;
-    const int bxi = brick / (nbz * nby);
+    const int bxl = brick / (nbz * nby);
+    const int bxi = bxl < nbx0 ? bx0 + bxl : bx1 + (bxl - nbx0);
     const int cx0 = bxi * CFG::BX, cy0 = byi * CFG::BY, cz0 = bzi * CFG::BZ;
     const int cx1 = min(cx0 + CFG::BX, d.nx), cy1 = min(cy0 + CFG::BY, d.ny), cz1 = min(cz0 + CFG::BZ, d.nz);  // excl.
     const int sx0 = max(cx0 - 1, 0), sy0 = max(cy0 - 1, 0), sz0 = max(cz0 - 1, 0);
@@ -383,7 +386,8 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nbx, int nb
             for (int k = 1; k < CFG::NZS; ++k)
                 if (k <= nzs) sCE[lane * CFG::NZS + k] = d.cell_end[base + k - 1];
             len = sCE[lane * CFG::NZS + nzs] - gstart;
-            if (ix >= cx0 && ix < cx1 && iy >= cy0 && iy < cy1 && ix >= d.tgt_lo && ix < d.tgt_hi) {
+            if (ix >= cx0 && ix < cx1 && iy >= cy0 && iy < cy1 &&
+                ((ix >= d.tgt_lo && ix < d.tgt_hi) || (ix >= d.tgt_lo2 && ix < d.tgt_hi2))) {
                 // targets: cells cz0 .. cz1-1 of this column (true start, also for flat cell 0)
                 tstart = (base + (cz0 - sz0) > 0) ? sCE[lane * CFG::NZS + (cz0 - sz0)] : 0;
                 tlen = sCE[lane * CFG::NZS + (cz1 - sz0)] - tstart;
@@ -619,13 +623,24 @@ static int launch_simple(SphContext* c, const int* list, int n) {
 }
 
 template <int MODE, class CFG>
-static int launch_brick_cfg(SphContext* c) {
+static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, int hi2 = 0) {
     DevView d = sph_view(c);
     if (MODE == GM_DENSITY_EOS) { d.tgt_lo = c->tgt_layers[0]; d.tgt_hi = c->tgt_layers[1]; }
     if (MODE == GM_FORCE_FUSED) { d.tgt_lo = c->tgt_layers[2]; d.tgt_hi = c->tgt_layers[3]; }
-    const int nbx = (d.nx + CFG::BX - 1) / CFG::BX, nby = (d.ny + CFG::BY - 1) / CFG::BY,
-              nbz = (d.nz + CFG::BZ - 1) / CFG::BZ;
-    const int nbricks = nbx * nby * nbz;
+    if (lo >= 0) { d.tgt_lo = lo; d.tgt_hi = hi; d.tgt_lo2 = lo2; d.tgt_hi2 = hi2; }
+    if (d.tgt_hi2 <= d.tgt_lo2) d.tgt_lo2 = d.tgt_hi2 = 0;
+    if (d.tgt_hi <= d.tgt_lo) { d.tgt_lo = d.tgt_lo2; d.tgt_hi = d.tgt_hi2; d.tgt_lo2 = d.tgt_hi2 = 0; }
+    if (d.tgt_hi <= d.tgt_lo) return 0;
+    // only the brick columns (in x) that overlap a target range are launched
+    int bx0 = d.tgt_lo / CFG::BX, e0 = (d.tgt_hi - 1) / CFG::BX + 1, bx1 = 0, e1 = 0;
+    if (d.tgt_hi2 > d.tgt_lo2) {
+        bx1 = d.tgt_lo2 / CFG::BX; e1 = (d.tgt_hi2 - 1) / CFG::BX + 1;
+        if (bx1 < bx0) { int t = bx0; bx0 = bx1; bx1 = t; t = e0; e0 = e1; e1 = t; }
+        if (bx1 < e0) { e0 = e1 > e0 ? e1 : e0; bx1 = e1 = 0; }  // groups touch: merge (a brick must run once)
+    }
+    const int nbx0 = e0 - bx0, nbx1 = e1 - bx1;
+    const int nby = (d.ny + CFG::BY - 1) / CFG::BY, nbz = (d.nz + CFG::BZ - 1) / CFG::BZ;
+    const int nbricks = (nbx0 + nbx1) * nby * nbz;
     const int per_xcd = (nbricks + 7) / 8;
     const int bytes = CFG::bytes(!mode_reads_list<MODE>());
     static bool attr_set = false;
@@ -634,20 +649,28 @@ static int launch_brick_cfg(SphContext* c) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gather_brick<MODE, CFG>), dim3(per_xcd * 8), dim3(TPB), bytes, c->stream, d, nbx, nby, nbz,
-                       nbricks, per_xcd, c->glist, c->gcnt, c->cap);
+    hipLaunchKernelGGL((k_gather_brick<MODE, CFG>), dim3(per_xcd * 8), dim3(TPB), bytes, c->stream, d, bx0, nbx0, bx1, nby,
+                       nbz, nbricks, per_xcd, c->glist, c->gcnt, c->cap);
     SPH_LAUNCH_CHECK(c);
     return 0;
 }
 
 template <int MODE>
-static int launch_brick(SphContext* c) {
+static int launch_brick(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, int hi2 = 0) {
     switch (c->opt_brick_shape) {
-        case 1: return launch_brick_cfg<MODE, Cfg1>(c);
-        case 2: return launch_brick_cfg<MODE, Cfg2>(c);
-        case 3: return launch_brick_cfg<MODE, Cfg3>(c);
-        default: return launch_brick_cfg<MODE, Cfg0>(c);
+        case 1: return launch_brick_cfg<MODE, Cfg1>(c, lo, hi, lo2, hi2);
+        case 2: return launch_brick_cfg<MODE, Cfg2>(c, lo, hi, lo2, hi2);
+        case 3: return launch_brick_cfg<MODE, Cfg3>(c, lo, hi, lo2, hi2);
+        default: return launch_brick_cfg<MODE, Cfg0>(c, lo, hi, lo2, hi2);
     }
+}
+
+// force sweep over the targets of x layers [lo, hi) only (slab mode: boundary layers first, interior later)
+int sphk_gather_layers(SphContext* c, int mode, int lo, int hi, int lo2, int hi2) {
+    if (c->N <= 0 || (hi <= lo && hi2 <= lo2)) return 0;
+    if (mode != GM_FORCE_FUSED || c->opt_gather_impl == 0) return sph_fail(c, SPH_E_INVALID, "layer-restricted sweeps need the brick force kernel");
+    if (hi < lo) hi = lo;
+    return launch_brick<GM_FORCE_FUSED>(c, lo, hi, lo2, hi2);
 }
 
 template <int MODE>

@@ -33,20 +33,41 @@ struct WallHi { float v[3]; };
 // WCSPH.py:143-149 advect; FLUID_WALLS additionally applies
 // enforce_boundary_3D(material_fluid) (sph_base.py:270-271) to fluid particles in
 // the same pass (it only touches fluid, so it commutes with the rigid solve).
+// one particle's symplectic-Euler update (+ fluid wall pass); shared by the in-place kernel and the packer
+template <bool FLUID_WALLS>
+__device__ __forceinline__ void advect_one(const DevView& d, const float hi[3], float4& xm, float4& vf, const float4 a) {
+    const int fl = __float_as_int(vf.w);
+    if (!sph_flags_dynamic(fl)) return;
+    vf.x += d.dt * a.x; vf.y += d.dt * a.y; vf.z += d.dt * a.z;
+    xm.x += d.dt * vf.x; xm.y += d.dt * vf.y; xm.z += d.dt * vf.z;
+    if (FLUID_WALLS && sph_is_fluid(fl)) wall_collide(d, hi, xm, vf);
+}
+
 template <bool FLUID_WALLS>
 __global__ __launch_bounds__(TPB) void k_advect(DevView d, WallHi hi) {
     const int i = blockIdx.x * TPB + threadIdx.x;
     if (i >= d.N) return;
     float4 vf = d.vf[i];
-    const int fl = __float_as_int(vf.w);
-    if (!sph_flags_dynamic(fl)) return;
+    if (!sph_flags_dynamic(__float_as_int(vf.w))) return;
     float4 xm = d.xm[i];
-    const float4 a = d.acc[i];
-    vf.x += d.dt * a.x; vf.y += d.dt * a.y; vf.z += d.dt * a.z;
-    xm.x += d.dt * vf.x; xm.y += d.dt * vf.y; xm.z += d.dt * vf.z;
-    if (FLUID_WALLS && sph_is_fluid(fl)) wall_collide(d, hi.v, xm, vf);
+    advect_one<FLUID_WALLS>(d, hi.v, xm, vf, d.acc[i]);
     d.xm[i] = xm;
     d.vf[i] = vf;
+}
+
+// Slab halo packer: records [first, first+count) AS THEY WILL BE after this step's advect, written to dst
+// (count xm, then count vf, then count aux) without touching the arrays -- the interior force sweep that runs
+// concurrently with the exchange still needs the old positions; k_advect later repeats the same update in place.
+__global__ __launch_bounds__(TPB) void k_pack_advected(DevView d, WallHi hi, int first, int count,
+                                                       float4* __restrict__ dst) {
+    const int k = blockIdx.x * TPB + threadIdx.x;
+    if (k >= count) return;
+    const int i = first + k;
+    float4 xm = d.xm[i], vf = d.vf[i];
+    advect_one<true>(d, hi.v, xm, vf, d.acc[i]);
+    dst[k] = xm;
+    dst[count + k] = vf;
+    dst[2 * count + k] = d.aux[i];
 }
 
 __global__ __launch_bounds__(TPB) void k_enforce_boundary(DevView d, WallHi hi, int particle_type,
@@ -348,6 +369,15 @@ int sphk_advect(SphContext* c, bool fused_fluid_walls) {
     const int nb = (c->N + TPB - 1) / TPB;
     if (fused_fluid_walls) hipLaunchKernelGGL(k_advect<true>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c));
     else hipLaunchKernelGGL(k_advect<false>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c));
+    SPH_LAUNCH_CHECK(c);
+    return 0;
+}
+
+int sphk_pack_advected(SphContext* c, int first, int count, void* dst) {
+    if (count <= 0) return 0;
+    DevView d = sph_view(c);
+    hipLaunchKernelGGL(k_pack_advected, dim3((count + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, wall_hi(c), first, count,
+                       (float4*)dst);
     SPH_LAUNCH_CHECK(c);
     return 0;
 }

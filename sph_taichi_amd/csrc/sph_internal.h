@@ -29,7 +29,8 @@ struct DevView {
     int N, G;
     int nx, ny, nz;
     int ox, oy, oz;  // cell_origin (multi-GPU slabs)
-    int tgt_lo, tgt_hi;  // local x layers whose particles are targets of this sweep
+    int tgt_lo, tgt_hi;  // local x layers whose particles are targets of this sweep ...
+    int tgt_lo2, tgt_hi2;  // ... plus an optional second range (slab mode: both boundary sets in one launch)
     int drop_outside;  // slab mode: x layer outside the local grid -> virtual cell G
     int ablate;      // debug: bit0 skip phase 2, bit1 skip list write-out, bit2 skip phase 1 (profiling only)
     float grid_size, h, inv_h, d, d2, m_V0, rho0, stiffness, exponent, sigma, dt;
@@ -60,6 +61,7 @@ struct SphContext {
     int cur;  // which ping-pong set is current
     int* h_pinned;       // 16 ints of pinned host memory for sph_layer_offsets_begin/_end
     hipEvent_t ev_off;   // recorded behind those copies
+    hipEvent_t ev_pack;  // recorded behind the halo packers of sph_slab_forces
     int off_zero_mask;   // which of the pending offsets are layer 0 (no copy needed)
     int tgt_layers[4];  // density lo/hi, force lo/hi (slab mode); default 0..nx
     int in_off;  // first live record of the current set (non-zero only between sph_select_range and the next sort)
@@ -117,6 +119,8 @@ int sphk_hash_histogram(SphContext* c);
 int sphk_scan(SphContext* c);
 int sphk_sort_scatter(SphContext* c, bool sort_acc);
 int sphk_gather(SphContext* c, int mode);
+int sphk_gather_layers(SphContext* c, int mode, int lo, int hi, int lo2, int hi2);  // brick sweep, targets in x layers [lo,hi) u [lo2,hi2)
+int sphk_pack_advected(SphContext* c, int first, int count, void* dst);
 int sphk_eos(SphContext* c);
 int sphk_advect(SphContext* c, bool fused_fluid_walls);
 int sphk_enforce_boundary(SphContext* c, int particle_type);

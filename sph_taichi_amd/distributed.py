@@ -188,6 +188,9 @@ class SlabSolver:
         self.nbuf = nbuf
         self.owned_range = None     # (first, count) of the owned particles in the current order
         self.off = None
+        self._need_density = True
+        self.has_dynamic = bool(dyn_blocks)
+        self.transport = None
         self.has_left, self.has_right = rank > 0, rank < world - 1
         self.stats = {"sent": 0, "received": 0}
 
@@ -205,60 +208,74 @@ class SlabSolver:
             self.recv_buf[side] = self.torch.empty(need, dtype=self.torch.uint8, device=self.tdev)
         return self.recv_buf[side]
 
-    # -- the two halves of a step around the exchange -------------------------
-    # One sort per step.  `self.off` holds, for the CURRENT order (the one the last sort produced, whose
-    # positions the sweeps have since advanced), the record offsets of the layer boundaries
-    #   [HALO, 2*HALO+1, nx-2*HALO-1, nx-HALO]
-    # so the ranges to send and the owned range are known on the host without touching the device.
-    def pre_exchange(self):
-        """Pack the boundary layers of the current order for both neighbours (no sort, no sync)."""
-        ps = self.ps
-        if self.off is None:          # first call: nothing sorted yet -> sort the initial (owned) particles
-            ps._call("sph_sort")
-            self._after_sort()
+    # -- step phases ---------------------------------------------------------------
+    # `self.off` holds, for the CURRENT order (the one the last sort produced), the record offsets of the layer
+    # boundaries [HALO, 2*HALO+1, nx-2*HALO-1, nx-HALO]: the ranges to send and the owned range are known on
+    # the host.  Per step:
+    #   phase_forces : force sweep of the boundary layers, halo packers (records as they will be after this
+    #                  step's advect), event; then interior force sweep + in-place advect keep the GPU busy
+    #   (exchange)   : starts as soon as the packers are done -> hidden behind the interior force sweep
+    #   phase_advance: keep the old owned range, append the neighbours' ranges, sort once (position decides
+    #                  ownership, strays fall into the virtual cell), density sweep; read the new offsets back
+    def next_counts(self):
         o = self.off
-        nL = (o[1] - o[0]) if self.has_left else 0        # old layers [HALO, 2*HALO+1)
-        nR = (o[3] - o[2]) if self.has_right else 0       # old layers [nx-2*HALO-1, nx-HALO)
-        for side, first, n in (("L", o[0], nL), ("R", o[2], nR)):
+        return ((o[1] - o[0]) if self.has_left else 0, (o[3] - o[2]) if self.has_right else 0)
+
+    def _ensure_send_bufs(self, nL, nR):
+        for side, n in (("L", nL), ("R", nR)):
             if n * RECORD_BYTES > self.send_buf[side].numel():
                 self.send_buf[side] = self.torch.empty(int(1.25 * n) * RECORD_BYTES, dtype=self.torch.uint8,
                                                        device=self.tdev)
-            if n > 0:
-                ps._call("sph_pack_range", first, n, C.c_void_p(self.send_buf[side].data_ptr()))
+
+    def init_pack(self):
+        """First halo exchange (initialize): sort the initial particles, pack the boundary layers as they are."""
+        ps = self.ps
+        ps._call("sph_sort")
+        self._read_offsets(begin=True)
+        nL, nR = self.next_counts()
+        self._ensure_send_bufs(nL, nR)
+        ps._call("sph_slab_pack", self.off[0], nL, C.c_void_p(self.send_buf["L"].data_ptr()),
+                 self.off[2], nR, C.c_void_p(self.send_buf["R"].data_ptr()))
         self.stats["sent"] += nL + nR
         return self.send_buf["L"], nL, self.send_buf["R"], nR
 
-    def post_exchange(self, recv_left, n_left, recv_right, n_right, sweeps=True, announce=False):
-        """Keep the previously owned range, append the neighbours' boundary layers, sort once (position
-        decides ownership; strays outside the local grid fall into the virtual cell and are dropped), sweep."""
+    def phase_forces(self):
+        ps = self.ps
+        if self._need_density:
+            ps._call("sph_slab_density")
+            self._need_density = False
+        nL, nR = self.next_counts()
+        self._ensure_send_bufs(nL, nR)
+        nx = self.nx_local
+        extra = 1 if self.has_dynamic else 0      # coupling reactions on boundary solids come from one layer further in
+        ps._call("sph_slab_forces", HALO, 2 * HALO + 1 + extra, nx - 2 * HALO - 1 - extra, nx - HALO,
+                 self.off[0], nL, C.c_void_p(self.send_buf["L"].data_ptr()),
+                 self.off[2], nR, C.c_void_p(self.send_buf["R"].data_ptr()))
+        ps._call("sph_slab_wait_pack")
+        self.stats["sent"] += nL + nR
+        return self.send_buf["L"], nL, self.send_buf["R"], nR
+
+    def phase_advance(self, recv_left, n_left, recv_right, n_right, density=True):
         ps = self.ps
         o = self.off
-        ps._call("sph_select_range", o[0], o[3] - o[0])   # old owned layers [HALO, nx-HALO)
-        for buf, n in ((recv_left, n_left), (recv_right, n_right)):
-            if n > 0:
-                ps._call("sph_append_records", C.c_void_p(buf.data_ptr()), n)
         self.stats["received"] += n_left + n_right
-        ps._call("sph_sort")
-        # read the layer offsets back behind the sort, but enqueue the sweeps before waiting for them:
-        # the GPU runs the sweeps while the host picks up the numbers (strays in the virtual cell are
-        # still in the particle count during the sweeps; no brick ever visits them)
-        self._after_sort(begin_only=True)
-        if sweeps:
-            ps._call("sph_sweeps")
-        self._after_sort(end_only=True)
-        if announce:                  # the next exchange's sizes are known now: tell the neighbours early
-            self.transport.start_counts(*self.next_counts())
+        nx = self.nx_local
+        layers = (C.c_int32 * 5)(HALO, 2 * HALO + 1, nx - 2 * HALO - 1, nx - HALO, nx)
+        ps._call("sph_slab_advance", o[0], o[3] - o[0],
+                 C.c_void_p(recv_left.data_ptr()) if n_left > 0 else None, n_left,
+                 C.c_void_p(recv_right.data_ptr()) if n_right > 0 else None, n_right, layers, 5, 2 if density else 0)
+        self._need_density = not density
+        self._read_offsets(begin=False)
+        if getattr(self, "transport", None) is not None and hasattr(self.transport, "start_counts"):
+            self.transport.start_counts(*self.next_counts())   # the next exchange's sizes are known now
 
-    def _after_sort(self, begin_only=False, end_only=False):
+    def _read_offsets(self, begin):
         nx = self.nx_local
         layers = [HALO, 2 * HALO + 1, nx - 2 * HALO - 1, nx - HALO, nx]
-        if not end_only:
-            arr = (C.c_int32 * len(layers))(*layers)
-            self.ps._call("sph_layer_offsets_begin", arr, len(layers))
-            if begin_only:
-                return
-        out = (C.c_int32 * len(layers))()
-        self.ps._call("sph_layer_offsets_end", out, len(layers))
+        if begin:
+            self.ps._call("sph_layer_offsets_begin", (C.c_int32 * 5)(*layers), 5)
+        out = (C.c_int32 * 5)()
+        self.ps._call("sph_layer_offsets_end", out, 5)
         o = list(out)
         self.ps._call("sph_truncate", o[4])               # drop the virtual cell
         self.off = o[:4]
@@ -268,23 +285,21 @@ class SlabSolver:
     def attach(self, transport):
         self.transport = transport
 
-    def step(self, n=1, sweeps=True):
-        for _ in range(n):
-            sL, nL, sR, nR = self.pre_exchange()
-            self.ps.sync()      # the packed ranges are written on the context's stream, RCCL reads on torch's
-            rL, mL, rR, mR = self.transport.exchange(sL if self.has_left else None, nL,
-                                                     sR if self.has_right else None, nR, self._alloc_recv)
-            self.post_exchange(rL, mL, rR, mR, sweeps=sweeps, announce=True)
+    def _exchange(self, sL, nL, sR, nR):
+        return self.transport.exchange(sL if self.has_left else None, nL, sR if self.has_right else None, nR,
+                                       self._alloc_recv)
 
-    def next_counts(self):
-        o = self.off
-        return ((o[1] - o[0]) if self.has_left else 0, (o[3] - o[2]) if self.has_right else 0)
+    def step(self, n=1):
+        for _ in range(n):
+            rL, mL, rR, mR = self._exchange(*self.phase_forces())
+            self.phase_advance(rL, mL, rR, mR)
 
     def initialize(self):
         """SPHBase.initialize() (sph_base.py:80-85) for a slab: neighbour structure with halos, then the
         static boundary volumes (ghost layer 1 sees complete neighbourhoods, so owned values are exact)."""
         self.solver._push()
-        self.step(1, sweeps=False)
+        rL, mL, rR, mR = self._exchange(*self.init_pack())
+        self.phase_advance(rL, mL, rR, mR, density=False)
         self.ps._call("sph_compute_boundary_volume", 0)
 
     # -- inspection (tests) ----------------------------------------------------
@@ -297,25 +312,32 @@ class SlabSolver:
 
 
 def run_local_slabs(solvers, n_steps, initialize=False):
-    """Drive P SlabSolvers that live in ONE process (one GPU) in lock-step."""
-    tr = LocalTransport(len(solvers))
+    """Drive P SlabSolvers that live in ONE process (one GPU) in lock-step; a neighbour's send buffer is read
+    directly (device pointer), which is all `LocalTransport` would do."""
+    P = len(solvers)
+
+    def swap(sent):
+        for r, s in enumerate(solvers):
+            s.ps.sync()
+        out = []
+        for r in range(P):
+            rl = (sent[r - 1][2], sent[r - 1][3]) if r > 0 else (None, 0)          # left neighbour's right range
+            rr = (sent[r + 1][0], sent[r + 1][1]) if r + 1 < P else (None, 0)
+            out.append((rl[0], rl[1], rr[0], rr[1]))
+        return out
+
     if initialize:
         for s in solvers:
             s.solver._push()
-    for it in range(n_steps):
-        sent = [s.pre_exchange() for s in solvers]
-        for s in solvers:
-            s.ps.sync()
-        for r, s in enumerate(solvers):
-            sL, nL, sR, nR = sent[r]
-            rl = (sent[r - 1][2], sent[r - 1][3]) if r > 0 else (None, 0)          # left neighbour's right range
-            rr = (sent[r + 1][0], sent[r + 1][1]) if r + 1 < len(solvers) else (None, 0)
-            s.post_exchange(rl[0], rl[1], rr[0], rr[1], sweeps=not initialize)
-        if initialize:
-            for s in solvers:
-                s.ps._call("sph_compute_boundary_volume", 0)
-            return
-    del tr
+        recv = swap([s.init_pack() for s in solvers])
+        for s, r in zip(solvers, recv):
+            s.phase_advance(*r, density=False)
+            s.ps._call("sph_compute_boundary_volume", 0)
+        return
+    for _ in range(n_steps):
+        recv = swap([s.phase_forces() for s in solvers])
+        for s, r in zip(solvers, recv):
+            s.phase_advance(*r)
 
 
 def gather_by_pid(solvers, name, n_global):
@@ -334,16 +356,18 @@ def gather_by_pid(solvers, name, n_global):
 # bench.py --gpus N  (weak scaling: every rank owns one ~1.74 M-particle slab)
 # ---------------------------------------------------------------------------
 def slab_bench_scene(world):
-    """BASELINE.md C4 family: (64*world) x 165 x 165 particles in a (2*world, 4, 3.4) tank;
-    world = 8 is C4 itself (512 x 165 x 165 = 13,939,200 particles, 400 x 100 x 85 cells)."""
+    """Weak-scaling family: `world` copies of BASELINE.md's C3' box side by side along x --
+    (246*world) x 74 x 96 particles in a (5*world, 3, 2) tank, so every rank's slab is exactly the N = 1
+    workload (1,747,584 particles, 125 x 75 x 50 cells) plus its halos; world = 8 gives 13,980,672 particles
+    (BASELINE.json: "13.9 M particles" on 8 GPUs)."""
     cfg = {
-        "domainStart": [0.0, 0.0, 0.0], "domainEnd": [2.0 * world, 4.0, 3.4], "particleRadius": 0.01,
+        "domainStart": [0.0, 0.0, 0.0], "domainEnd": [5.0 * world, 3.0, 2.0], "particleRadius": 0.01,
         "numberOfStepsPerRenderUpdate": 1, "density0": 1000, "simulationMethod": 0,
         "gravitation": [0.0, -9.81, 0.0], "timeStepSize": 0.0004, "stiffness": 50000, "exponent": 7,
         "boundaryHandlingMethod": 0, "exportFrame": False, "exportPly": False, "exportObj": False,
     }
     d = 0.02
-    counts = (64 * world, 165, 165)
+    counts = (246 * world, 74, 96)
     corner = (0.04, 0.04, 0.04)
     end = [c + (n - 0.5) * d for c, n in zip(corner, counts)]
     return {"Configuration": cfg,
@@ -361,10 +385,12 @@ def run_slab_bench(args, rank, world, local_rank):
     s.attach(TorchTransport(torch.device("cuda", local_rank)))
     s.initialize()
     s.step(args.warmup)
+    s.ps.sync()
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
     s.step(args.steps)
+    s.ps.sync()
     torch.cuda.synchronize()
     dist.barrier()
     red_dev = torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else torch.device("cpu")
@@ -380,7 +406,7 @@ def run_slab_bench(args, rank, world, local_rank):
         "value": round(steps_per_s * n_global / REF_PARTICLES, 3), "unit": "steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"c4_family_dambreak_{64 * world}x165x165", "particles": n_global,
+        "config": {"workload": f"c3p_tiled_x{world}_{246 * world}x74x96", "particles": n_global,
                    "particles_owned_sum": int(own.item()), "cuts": s.cuts, "halo_layers": HALO,
                    "sent_records_per_step": round(s.stats["sent"] / max(args.steps + args.warmup + 1, 1), 1),
                    "backend": dist.get_backend(),

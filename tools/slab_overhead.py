@@ -1,0 +1,24 @@
+"""How much does the slab driver's per-step host logic cost?  world = 1 (no neighbours, no messages) against the
+plain device loop on the same scene."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from sph_taichi_amd import ParticleSystem, SimConfig, _lib
+from sph_taichi_amd.distributed import SlabSolver, slab_bench_scene, LocalTransport
+import copy
+
+sd, n = slab_bench_scene(1)
+ps = ParticleSystem(SimConfig(config=copy.deepcopy(sd)))
+solver = ps.build_solver(); solver.initialize(); solver.step(10); ps.sync()
+t0 = time.perf_counter(); solver.step(100); ps.sync(); t1 = time.perf_counter()
+print(f"plain sph_step            : {(t1 - t0) * 10:.3f} ms/step  ({n} particles)")
+ps.close()
+
+class NoTransport:
+    def start_counts(self, a, b): self._pending = None
+    def exchange(self, sL, nL, sR, nR, alloc): return None, 0, None, 0
+s = SlabSolver(sd, 0, 1, device=0)
+s.attach(NoTransport()); s.initialize(); s.step(10); s.ps.sync()
+t0 = time.perf_counter(); s.step(100); s.ps.sync(); t1 = time.perf_counter()
+print(f"SlabSolver world=1 (no msg): {(t1 - t0) * 10:.3f} ms/step")
+s.close()

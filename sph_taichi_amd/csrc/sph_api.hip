@@ -25,12 +25,12 @@ DevView sph_view(const SphContext* c) {
     d.ablate = c->opt_ablate;
     d.drop_outside = c->opt_drop_outside;
     d.ox = p.cell_origin[0]; d.oy = p.cell_origin[1]; d.oz = p.cell_origin[2];
-    d.grid_size = p.grid_size; d.h = p.support_radius; d.inv_h = 1.0f / p.support_radius; d.d = p.particle_diameter;
+    d.grid_size = p.grid_size; d.h = p.support_radius; d.inv_h = 1.0f / p.support_radius;
     d.d2 = p.particle_diameter * p.particle_diameter;  // WCSPH.py:96
     d.m_V0 = p.m_V0; d.rho0 = p.density_0; d.stiffness = p.stiffness; d.exponent = p.exponent;
     d.sigma = p.surface_tension; d.dt = p.dt;
     d.gx = p.g[0]; d.gy = p.g[1]; d.gz = p.g[2];
-    d.domx = p.domain_size[0]; d.domy = p.domain_size[1]; d.domz = p.domain_size[2]; d.pad = p.padding;
+    d.pad = p.padding;
     d.k_w = p.k_w; d.k_dw = p.k_dw; d.visc_d_nu = p.visc_d_nu; d.visc_eps = p.visc_eps;
     d.w_zero = p.k_w * (6.0f * 0.0f - 6.0f * 0.0f + 1.0f);  // W(0), sph_base.py:41
     {   // W(d): q = d/h (sph_base.py:36-44)

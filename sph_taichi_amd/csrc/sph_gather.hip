@@ -34,6 +34,7 @@ struct Target {
     float px, py, pz;      // pressure accumulator
     float st_c;            // surface_tension / m_i
     float dpj_solid;       // p_i / rho0^2 (WCSPH.py:60)
+    bool self_in_sum;      // density: the brick path sums the self pair (= m_V_i W(0)) with the neighbours
 };
 
 template <int MODE>
@@ -82,6 +83,7 @@ __device__ __forceinline__ void target_init(const DevView& d, Target& t, const f
     t.ax = d.gx; t.ay = d.gy; t.az = d.gz;  // WCSPH.py:135-136 d_v = g
     t.px = t.py = t.pz = 0.0f;
     t.m = t.rho = t.p = t.dpi = t.st_c = t.dpj_solid = 0.0f;
+    t.self_in_sum = false;
     if (MODE == GM_NONPRESSURE || MODE == GM_PRESSURE) {
         t.m = E.x; t.rho = E.y; t.p = E.z;
         t.dpi = E.z / (E.y * E.y);  // WCSPH.py:49
@@ -181,14 +183,14 @@ __device__ __forceinline__ void target_finish(const DevView& d, Target& t, int i
     }
     if (MODE == GM_DENSITY) {
         // WCSPH.py:39-43
-        if (gathered) reinterpret_cast<float*>(&d.aux[i])[1] = (t.mV * d.w_zero + t.s0) * d.rho0;
+        if (gathered) reinterpret_cast<float*>(&d.aux[i])[1] = (t.self_in_sum ? t.s0 : t.mV * d.w_zero + t.s0) * d.rho0;
         return;
     }
     if (MODE == GM_DENSITY_EOS) {
         float4 aux = d.aux[i];
         float4 e;
         if (gathered) {
-            const float rho_raw = (t.mV * d.w_zero + t.s0) * d.rho0;  // WCSPH.py:39-43
+            const float rho_raw = (t.self_in_sum ? t.s0 : t.mV * d.w_zero + t.s0) * d.rho0;  // WCSPH.py:39-43
             const float rho = fmaxf(rho_raw, d.rho0);                 // WCSPH.py:75
             const float p = d.stiffness * (powf(rho / d.rho0, d.exponent) - 1.0f);  // WCSPH.py:76
             e = make_float4(p / (rho * rho), aux.x / rho_raw, aux.x, rho);
@@ -520,24 +522,33 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int bx0, int nb
                             if (cnt < CFG::LISTCAP) gl[(size_t)cnt * cap] = (unsigned short)(tagbase + bit);
                             ++cnt;
                             if (mode_inline_physics<MODE>()) {
-                                // the density pair term is cheap: do it here instead of re-reading the list
+                                // The density pair term is cheap: do it here instead of re-reading the list, and
+                                // branch-free: (1-q) is clamped at 0, so W vanishes for r >= h exactly as if the
+                                // pair had been rejected (particle_system.py:385); the self pair (r = 0) supplies
+                                // the m_V_i W(0) term of WCSPH.py:39.
                                 const int j = base + (int)bit;
-                                const float4 q = sQ[j];
-                                const float rx = fmaf(0.5f, q.x, txl_), ry = fmaf(0.5f, q.y, tyl_), rz = fmaf(0.5f, q.z, tzl_);
+                                const float4 q4 = sQ[j];
+                                const float rx = fmaf(0.5f, q4.x, txl_), ry = fmaf(0.5f, q4.y, tyl_), rz = fmaf(0.5f, q4.z, tzl_);
                                 const float r2 = rx * rx + ry * ry + rz * rz;
-                                const float rinv = sph_rsq(r2);
-                                const float rn = r2 * rinv;
-                                if (rn < d.h && j != li)  // particle_system.py:385
-                                    pair_physics<MODE>(d, t, rx, ry, rz, r2, rn, rinv, make_float4(0.f, 0.f, 0.f, sW[j]),
-                                                       make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), 0);
+                                const float qn = r2 * sph_rsq(r2) * d.inv_h;
+                                const float tq = fmaxf(1.0f - qn, 0.0f);
+                                const float inner = d.k_w * ((6.0f * qn - 6.0f) * qn * qn + 1.0f);
+                                const float outer = d.k_w * 2.0f * (tq * tq * tq);
+                                t.s0 += sW[j] * (qn <= 0.5f ? inner : outer);
                             }
                         }
                     }
 #undef SPH_TEST
                 }
             }
-            if (cnt > CFG::LISTCAP && !(d.ablate & 8)) walk = true;  // list overflow (extreme compression): exact slow path
-            if (mode_writes_list<MODE>()) gcnt[gi] = (unsigned char)(walk ? SPH_CNT_WALK : cnt);
+            // list overflow (extreme compression): the list-reading sweep must take the exact slow path; this
+            // sweep too, unless its pair term was already summed inline (complete regardless of the list length)
+            const bool list_ovf = cnt > CFG::LISTCAP && !(d.ablate & 8);
+            // (flat cell 0's own range is never visited -- the reference's max(0, idx-1) quirk -- so a target that
+            // lives there does not meet itself in the list and keeps the explicit self term)
+            if (mode_inline_physics<MODE>()) t.self_in_sum = key_i != 0;
+            else if (list_ovf) walk = true;
+            if (mode_writes_list<MODE>()) gcnt[gi] = (unsigned char)((walk || list_ovf) ? SPH_CNT_WALK : cnt);
             __threadfence_block();  // this lane re-reads its own entries below
         }
         if (mode_reads_list<MODE>() && g && !overflow) {

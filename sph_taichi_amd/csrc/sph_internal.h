@@ -33,9 +33,9 @@ struct DevView {
     int tgt_lo2, tgt_hi2;  // ... plus an optional second range (slab mode: both boundary sets in one launch)
     int drop_outside;  // slab mode: x layer outside the local grid -> virtual cell G
     int ablate;      // debug: bit0 skip phase 2, bit1 skip list write-out, bit2 skip phase 1 (profiling only)
-    float grid_size, h, inv_h, d, d2, m_V0, rho0, stiffness, exponent, sigma, dt;
+    float grid_size, h, inv_h, d2, m_V0, rho0, stiffness, exponent, sigma, dt;
     float gx, gy, gz;
-    float domx, domy, domz, pad;
+    float pad;
     float k_w, k_dw, visc_d_nu, visc_eps;
     float w_zero, w_d;  // W(0), W(d)
     float4* xm;
@@ -162,43 +162,6 @@ __device__ __forceinline__ int sph_cell_coord(float p, float grid_size, int orig
 // particle_system.py:292-294 flatten_grid_index (z fastest)
 __device__ __forceinline__ int sph_flatten(const DevView& d, int cx, int cy, int cz) {
     return (cx * d.ny + cy) * d.nz + cz;
-}
-
-// sph_base.py:23-44 cubic_kernel
-__device__ __forceinline__ float sph_W(const DevView& d, float r_norm) {
-    float res = 0.0f;
-    const float q = r_norm / d.h;
-    if (q <= 1.0f) {
-        if (q <= 0.5f) {
-            const float q2 = q * q;
-            const float q3 = q2 * q;
-            res = d.k_w * (6.0f * q3 - 6.0f * q2 + 1.0f);
-        } else {
-            const float t = 1.0f - q;
-            res = d.k_w * 2.0f * (t * t * t);  // ti.pow(1-q, 3.0)
-        }
-    }
-    return res;
-}
-
-// sph_base.py:46-68 cubic_kernel_derivative; r_norm = |r| supplied by the caller
-__device__ __forceinline__ float3 sph_gradW(const DevView& d, float rx, float ry, float rz, float r_norm) {
-    float3 res = make_float3(0.0f, 0.0f, 0.0f);
-    const float q = r_norm / d.h;
-    if (r_norm > 1e-5f && q <= 1.0f) {
-        const float inv = r_norm * d.h;
-        float c;
-        if (q <= 0.5f) {
-            c = d.k_dw * q * (3.0f * q - 2.0f);
-        } else {
-            const float f = 1.0f - q;
-            c = d.k_dw * (-f * f);
-        }
-        res.x = c * (rx / inv);
-        res.y = c * (ry / inv);
-        res.z = c * (rz / inv);
-    }
-    return res;
 }
 
 // wave64 inclusive scan (the wavefront primitive replacing scan_single_buffer.py:4-29's

@@ -52,6 +52,12 @@ WORKLOADS = {
 
 
 def scene_dict(workload: str):
+    if workload in ("c2_dragon_bath", "c3_armadillo_equiv"):
+        # the reference's two demo scenes with their bodies taken from the committed voxel fixtures
+        # (tests/golden/*.npy; /root/reference does not exist on the GPU box)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import test_gpu_fullsize as fs
+        return fs.dragon_bath_scene() if workload == "c2_dragon_bath" else fs.armadillo_equiv_scene(body_y=2.0)
     dom, counts, corner = WORKLOADS[workload]
     cfg = copy.deepcopy(CFG)
     cfg["domainEnd"] = dom
@@ -75,7 +81,8 @@ def cpu_baseline(sd, sample_steps: int):
                   density_0=cfg.get_cfg("density0"), stiffness=cfg.get_cfg("stiffness"),
                   exponent=cfg.get_cfg("exponent"), dt=cfg.get_cfg("timeStepSize"), g=cfg.get_cfg("gravitation"))
     threads = max_threads()
-    o = Oracle(params, sc.arrays, n_objects=1, omp_threads=threads)
+    o = Oracle(params, sc.arrays, n_objects=max(sc.n_objects, 1), rigid_body_ids=sorted(sc.object_id_rigid_body),
+               dynamic_ids=sorted(sc.dynamic_rigid_ids), omp_threads=threads)
     o.initialize()
     o.step(1)                                   # warm-up (page faults, first sort)
     t0 = time.perf_counter()
@@ -95,7 +102,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c3p_uniform_1.75M", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c3p_uniform_1.75M",
+                    choices=sorted(WORKLOADS) + ["c2_dragon_bath", "c3_armadillo_equiv"])
     ap.add_argument("--gather-impl", type=int, default=1)
     ap.add_argument("--brick-shape", type=int, default=0)
     ap.add_argument("--fused", type=int, default=1)

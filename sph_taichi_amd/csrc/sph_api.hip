@@ -125,6 +125,10 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     rc = rc ? rc : alloc_dev(c, (void**)&c->scan_sums, (size_t)(c->scan_blocks + 1) * 4);
     rc = rc ? rc : alloc_dev(c, (void**)&c->glist, cap * 2 * SPH_GLIST_ROWS);
     rc = rc ? rc : alloc_dev(c, (void**)&c->gcnt, cap);
+    // smallest compiled brick is 2x2x4 cells
+    c->brick_cap = ((params->grid_num[0] + 1) / 2) * ((params->grid_num[1] + 1) / 2) * ((params->grid_num[2] + 3) / 4) + 8;
+    rc = rc ? rc : alloc_dev(c, (void**)&c->brick_list, (size_t)c->brick_cap * 4);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->brick_count, 16);
     const size_t cold = params->cold_capacity > 0 ? (size_t)params->cold_capacity : cap;
     if (cold < cap) { sph_destroy(c); return sph_fail(nullptr, SPH_E_INVALID, "sph_create: cold_capacity < capacity"); }
     c->cold_cap = (int)cold;
@@ -161,7 +165,7 @@ int32_t sph_destroy(SphContext* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->xm[0], c->xm[1], c->vf[0], c->vf[1], c->aux[0], c->aux[1], c->key[0], c->key[1], c->eos, c->acc,
                     c->acc_tmp, c->cell_end, c->rank_off, c->idx_unstable, c->scan_sums, c->x0_cold, c->color_cold,
-                    c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->rigid_accum, c->rigid_R, c->stage, c->glist, c->gcnt};
+                    c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->rigid_accum, c->rigid_R, c->stage, c->glist, c->gcnt, c->brick_list, c->brick_count};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < SPH_MAX_TIMED_STEPS; ++s)
         for (int k = 0; k < 5; ++k) if (c->ev[s][k]) (void)hipEventDestroy(c->ev[s][k]);

@@ -335,9 +335,37 @@ struct BrickCfg {
     static_assert(bytes(false) <= 32768, "force sweep: five workgroups per CU");
 };
 
+// Non-empty bricks of one sweep: a brick is listed iff it holds at least one particle of a target layer.  The
+// gather kernel is persistent and walks this list, so (1) empty regions of the domain cost nothing and (2) the
+// per-XCD chunks are chunks of WORK: a fluid that fills a corner of the tank still loads all 8 XCDs evenly.
+template <class CFG>
+__global__ __launch_bounds__(TPB) void k_brick_list(DevView d, int nbx, int nby, int nbz, int* __restrict__ list,
+                                                    int* __restrict__ count) {
+    const int b = blockIdx.x * TPB + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool has = false;
+    if (b < nbx * nby * nbz) {
+        const int bzi = b % nbz, byi = (b / nbz) % nby, bxi = b / (nbz * nby);
+        const int cx0 = bxi * CFG::BX, cy0 = byi * CFG::BY, cz0 = bzi * CFG::BZ;
+        const int cx1 = min(cx0 + CFG::BX, d.nx), cy1 = min(cy0 + CFG::BY, d.ny), cz1 = min(cz0 + CFG::BZ, d.nz);
+        for (int ix = cx0; ix < cx1 && !has; ++ix) {
+            if (!((ix >= d.tgt_lo && ix < d.tgt_hi) || (ix >= d.tgt_lo2 && ix < d.tgt_hi2))) continue;
+            for (int iy = cy0; iy < cy1 && !has; ++iy) {
+                const int lo = sph_flatten(d, ix, iy, cz0), hi = sph_flatten(d, ix, iy, cz1 - 1);
+                has = d.cell_end[hi] > (lo > 0 ? d.cell_end[lo - 1] : 0);
+            }
+        }
+    }
+    const unsigned long long m = __ballot(has);
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(count, __popcll(m));
+    base = __shfl(base, 0, 64);
+    if (has) list[base + __popcll(m & ((1ull << lane) - 1ull))] = b;
+}
+
 template <int MODE, class CFG>
-__global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int bx0, int nbx0, int bx1, int nby, int nbz,
-                                                      int nbricks, int bricks_per_xcd,
+__global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nbz, const int* __restrict__ brick_list,
+                                                      const int* __restrict__ brick_count,
                                                       unsigned short* __restrict__ glist,
                                                       unsigned char* __restrict__ gcnt, int cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -356,16 +384,19 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int bx0, int nb
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    // XCD-aware brick order: hardware block b runs on XCD b%8; give each XCD a
-    // contiguous run of bricks so neighbouring bricks share that XCD's L2.
-    const int b = blockIdx.x;
-    const int brick = (b & 7) * bricks_per_xcd + (b >> 3);
-    if (brick >= nbricks) return;
-    // the launch enumerates two groups of brick columns in x: [bx0, bx0+nbx0) then [bx1, ...)
+    // One workgroup per LISTED brick (the hardware scheduler balances them).  Hardware block b runs on XCD b%8:
+    // XCD x takes the x-th eighth of the list, so neighbouring bricks share that XCD's L2 and -- because the list
+    // holds work, not space -- all 8 XCDs are loaded evenly however the fluid sits in the tank.  The grid is sized
+    // for the worst case (every brick non-empty); surplus blocks leave here.
+    const int nb = *brick_count;
+    const int chunk = (nb + 7) >> 3;
+    const int kb = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk || kb >= nb) return;
+    {
+    const int brick = brick_list[kb];
     const int bzi = brick % nbz;
     const int byi = (brick / nbz) % nby;
-    const int bxl = brick / (nbz * nby);
-    const int bxi = bxl < nbx0 ? bx0 + bxl : bx1 + (bxl - nbx0);
+    const int bxi = brick / (nbz * nby);
     const int cx0 = bxi * CFG::BX, cy0 = byi * CFG::BY, cz0 = bzi * CFG::BZ;
     const int cx1 = min(cx0 + CFG::BX, d.nx), cy1 = min(cy0 + CFG::BY, d.ny), cz1 = min(cz0 + CFG::BZ, d.nz);  // excl.
     const int sx0 = max(cx0 - 1, 0), sy0 = max(cy0 - 1, 0), sz0 = max(cz0 - 1, 0);
@@ -603,6 +634,7 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int bx0, int nb
         }
         target_finish<MODE>(d, t, gi, g);
     }
+    }
 }
 
 // EOS alone (first loop of compute_pressure_forces, WCSPH.py:71-76)
@@ -642,17 +674,10 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
     if (d.tgt_hi2 <= d.tgt_lo2) d.tgt_lo2 = d.tgt_hi2 = 0;
     if (d.tgt_hi <= d.tgt_lo) { d.tgt_lo = d.tgt_lo2; d.tgt_hi = d.tgt_hi2; d.tgt_lo2 = d.tgt_hi2 = 0; }
     if (d.tgt_hi <= d.tgt_lo) return 0;
-    // only the brick columns (in x) that overlap a target range are launched
-    int bx0 = d.tgt_lo / CFG::BX, e0 = (d.tgt_hi - 1) / CFG::BX + 1, bx1 = 0, e1 = 0;
-    if (d.tgt_hi2 > d.tgt_lo2) {
-        bx1 = d.tgt_lo2 / CFG::BX; e1 = (d.tgt_hi2 - 1) / CFG::BX + 1;
-        if (bx1 < bx0) { int t = bx0; bx0 = bx1; bx1 = t; t = e0; e0 = e1; e1 = t; }
-        if (bx1 < e0) { e0 = e1 > e0 ? e1 : e0; bx1 = e1 = 0; }  // groups touch: merge (a brick must run once)
-    }
-    const int nbx0 = e0 - bx0, nbx1 = e1 - bx1;
-    const int nby = (d.ny + CFG::BY - 1) / CFG::BY, nbz = (d.nz + CFG::BZ - 1) / CFG::BZ;
-    const int nbricks = (nbx0 + nbx1) * nby * nbz;
-    const int per_xcd = (nbricks + 7) / 8;
+    const int nbx = (d.nx + CFG::BX - 1) / CFG::BX, nby = (d.ny + CFG::BY - 1) / CFG::BY,
+              nbz = (d.nz + CFG::BZ - 1) / CFG::BZ;
+    const int nbricks = nbx * nby * nbz;
+    if (nbricks > c->brick_cap) return sph_fail(c, SPH_E_INVALID, "brick list capacity exceeded");
     const int bytes = CFG::bytes(!mode_reads_list<MODE>());
     static bool attr_set = false;
     if (!attr_set) {
@@ -660,8 +685,13 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_gather_brick<MODE, CFG>), dim3(per_xcd * 8), dim3(TPB), bytes, c->stream, d, bx0, nbx0, bx1, nby,
-                       nbz, nbricks, per_xcd, c->glist, c->gcnt, c->cap);
+    const int grid = (nbricks + 7) / 8 * 8;
+    SPH_HIP(c, hipMemsetAsync(c->brick_count, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL((k_brick_list<CFG>), dim3((nbricks + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, nbx, nby, nbz,
+                       c->brick_list, c->brick_count);
+    SPH_LAUNCH_CHECK(c);
+    hipLaunchKernelGGL((k_gather_brick<MODE, CFG>), dim3(grid), dim3(TPB), bytes, c->stream, d, nby, nbz, c->brick_list,
+                       c->brick_count, c->glist, c->gcnt, c->cap);
     SPH_LAUNCH_CHECK(c);
     return 0;
 }

@@ -78,6 +78,9 @@ struct SphContext {
     int* scan_sums;    // block sums for the scan
     unsigned short* glist;  // [SPH_GLIST_ROWS * cap] neighbour lists handed from the density to the force sweep
     unsigned char* gcnt;    // [cap] list lengths (255 = take the global cell walk)
+    int* brick_list;        // [brick_cap] non-empty bricks of the sweep being launched
+    int* brick_count;       // device counter
+    int brick_cap;
     int scan_blocks;
     float* x0_cold;    // [3*cap]
     int* color_cold;   // [3*cap]

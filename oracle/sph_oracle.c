@@ -476,7 +476,7 @@ static void polar_rotation(const float A_[9], float R_[9]) {
     }
     for (int sweep = 0; sweep < 60; ++sweep) {
         double off = fabs(S[0][1]) + fabs(S[0][2]) + fabs(S[1][2]);
-        if (off < 1e-300) break;
+        if (off <= 1e-30 * (fabs(S[0][0]) + fabs(S[1][1]) + fabs(S[2][2])) + 1e-300) break;  /* cyclic Jacobi: quadratic, ~6 sweeps */
         for (int p = 0; p < 2; ++p) for (int q = p + 1; q < 3; ++q) {
             if (fabs(S[p][q]) < 1e-300) continue;
             double theta = (S[q][q] - S[p][p]) / (2.0 * S[p][q]);

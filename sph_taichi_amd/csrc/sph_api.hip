@@ -137,7 +137,8 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     rc = rc ? rc : alloc_dev(c, (void**)&c->rigid_rest_cm, (size_t)(params->n_objects > 0 ? params->n_objects : 1) * 12);
     rc = rc ? rc : alloc_dev(c, (void**)&c->dyn_list, cap * 4);
     rc = rc ? rc : alloc_dev(c, (void**)&c->dyn_count, 16);
-    rc = rc ? rc : alloc_dev(c, (void**)&c->rigid_accum, 16 * sizeof(double));
+    c->rigid_part_blocks = (c->cap + 255) / 256 + 1;
+    rc = rc ? rc : alloc_dev(c, (void**)&c->rigid_part, (size_t)c->rigid_part_blocks * 16 * sizeof(double));
     rc = rc ? rc : alloc_dev(c, (void**)&c->rigid_R, 16 * sizeof(float));
     c->stage_bytes = cap * 16 > (size_t)c->G * 4 ? cap * 16 : (size_t)c->G * 4;
     rc = rc ? rc : alloc_dev(c, &c->stage, c->stage_bytes);
@@ -165,7 +166,7 @@ int32_t sph_destroy(SphContext* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->xm[0], c->xm[1], c->vf[0], c->vf[1], c->aux[0], c->aux[1], c->key[0], c->key[1], c->eos, c->acc,
                     c->acc_tmp, c->cell_end, c->rank_off, c->idx_unstable, c->scan_sums, c->x0_cold, c->color_cold,
-                    c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->rigid_accum, c->rigid_R, c->stage, c->glist, c->gcnt, c->brick_list, c->brick_count};
+                    c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->rigid_part, c->rigid_R, c->stage, c->glist, c->gcnt, c->brick_list, c->brick_count};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < SPH_MAX_TIMED_STEPS; ++s)
         for (int k = 0; k < 5; ++k) if (c->ev[s][k]) (void)hipEventDestroy(c->ev[s][k]);
@@ -412,11 +413,8 @@ int32_t sph_compute_com(SphContext* c, int32_t object_id, float* cm_out) {
     int rc = refresh_dyn(c);
     rc = rc ? rc : sphk_rigid_com(c, object_id, false);
     if (rc) return rc;
-    double acc[4];
-    SPH_HIP(c, hipMemcpyAsync(acc, c->rigid_accum, sizeof(acc), hipMemcpyDeviceToHost, c->stream));
+    SPH_HIP(c, hipMemcpyAsync(cm_out, c->rigid_R, 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     SPH_HIP(c, hipStreamSynchronize(c->stream));
-    const float sum_m = (float)acc[0];
-    for (int k = 0; k < 3; ++k) cm_out[k] = (float)acc[1 + k] / sum_m;
     return 0;
 }
 

@@ -85,16 +85,56 @@ __global__ __launch_bounds__(TPB) void k_enforce_boundary(DevView d, WallHi hi, 
 }
 
 // ---- rigid bodies -----------------------------------------------------------
-// accum[0] = sum m, accum[1..3] = sum m x, accum[4..12] = A (row-major)
+// Shape matching sums as a deterministic two-stage reduction: every block writes its partial sums to
+// part[block][16] ([0] = sum m, [1..3] = sum m x, [4..12] = A row-major); consumers add the partials up in block
+// order.  No atomics, so the result does not depend on scheduling (the reference's f32 atomic sums do).
+#define RIGID_PART 16
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
 }
 
-// sph_base.py:182-192 compute_com (mass = m_V0 * density)
+// block-wide sum of NV values per thread -> part[blockIdx][off + k]
+template <int NV>
+__device__ __forceinline__ void block_store_partials(const double (&s)[NV], double* __restrict__ part, int off) {
+    __shared__ double red[TPB / 64][NV];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const double w = wave_sum(s[k]);
+        if (lane == 0) red[wave][k] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < TPB / 64; ++w) t += red[w][threadIdx.x];
+        part[(size_t)blockIdx.x * RIGID_PART + off + threadIdx.x] = t;
+    }
+}
+
+// total of partial component k over nblk blocks, computed by every thread that asks (small nblk, L2-resident)
+__device__ __forceinline__ void sum_partials(const double* __restrict__ part, int nblk, int off, int nv, double* out,
+                                             double* s_tmp) {
+    // wave 0 reduces: lane-strided over blocks
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        for (int k = 0; k < nv; ++k) {
+            double t = 0.0;
+            for (int bIdx = lane; bIdx < nblk; bIdx += 64) t += part[(size_t)bIdx * RIGID_PART + off + k];
+            t = wave_sum(t);
+            if (lane == 0) s_tmp[k] = t;
+        }
+    }
+    __syncthreads();
+    for (int k = 0; k < nv; ++k) out[k] = s_tmp[k];
+    __syncthreads();
+}
+
+// sph_base.py:182-192 compute_com (mass = m_V0 * density): per-block partial sums
 __global__ __launch_bounds__(TPB) void k_rigid_sum(DevView d, const int* __restrict__ list, int n, int object_id,
-                                                   double* __restrict__ accum) {
+                                                   double* __restrict__ part) {
     const int tix = blockIdx.x * TPB + threadIdx.x;
     double s[4] = {0, 0, 0, 0};
     if (tix < n) {
@@ -106,24 +146,23 @@ __global__ __launch_bounds__(TPB) void k_rigid_sum(DevView d, const int* __restr
             s[0] = mass; s[1] = (double)(mass * xm.x); s[2] = (double)(mass * xm.y); s[3] = (double)(mass * xm.z);
         }
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const double w = wave_sum(s[k]);
-        if ((threadIdx.x & 63) == 0 && w != 0.0) unsafeAtomicAdd(&accum[k], w);
-    }
+    block_store_partials<4>(s, part, 0);
 }
 
-// sph_base.py:206-210: A = sum m (x - cm) (x_0 - cm_rest)^T
+// sph_base.py:206-210: A = sum m (x - cm) (x_0 - cm_rest)^T, per-block partials
 __global__ __launch_bounds__(TPB) void k_rigid_A(DevView d, const int* __restrict__ list, int n, int object_id,
-                                                 double* __restrict__ accum) {
+                                                 double* __restrict__ part, int nblk) {
+    __shared__ double s_tmp[16];
+    double tot[4];
+    sum_partials(part, nblk, 0, 4, tot, s_tmp);
     const int tix = blockIdx.x * TPB + threadIdx.x;
     double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (tix < n) {
         const int i = list[tix];
         const int fl = __float_as_int(d.vf[i].w);
         if (sph_is_dynamic_rigid(fl) && sph_flags_object(fl) == object_id) {
-            const float sum_m = (float)accum[0];  // same f32 division as k_rigid_finalize
-            const float cm[3] = {(float)accum[1] / sum_m, (float)accum[2] / sum_m, (float)accum[3] / sum_m};
+            const float sum_m = (float)tot[0];  // f32 division like the reference's cm /= sum_m
+            const float cm[3] = {(float)tot[1] / sum_m, (float)tot[2] / sum_m, (float)tot[3] / sum_m};
             const float4 xm = d.xm[i];
             const float4 aux = d.aux[i];
             const int pid = __float_as_int(aux.w);
@@ -138,11 +177,7 @@ __global__ __launch_bounds__(TPB) void k_rigid_A(DevView d, const int* __restric
                 for (int b = 0; b < 3; ++b) s[3 * a + b] = (double)(w * (p[a] * q[b]));
         }
     }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const double w = wave_sum(s[k]);
-        if ((threadIdx.x & 63) == 0 && w != 0.0) unsafeAtomicAdd(&accum[4 + k], w);
-    }
+    block_store_partials<9>(s, part, 4);
 }
 
 // Rotation factor of A = R S (ti.polar_decompose, sph_base.py:212: third-party
@@ -157,7 +192,7 @@ __device__ void polar_rotation(const double A[3][3], float R_[9]) {
         }
     for (int sweep = 0; sweep < 60; ++sweep) {
         const double off = fabs(S[0][1]) + fabs(S[0][2]) + fabs(S[1][2]);
-        if (off < 1e-300) break;
+        if (off <= 1e-30 * (fabs(S[0][0]) + fabs(S[1][1]) + fabs(S[2][2])) + 1e-300) break;  // cyclic Jacobi: quadratic, ~6 sweeps
         for (int p = 0; p < 2; ++p)
             for (int q = p + 1; q < 3; ++q) {
                 if (fabs(S[p][q]) < 1e-300) continue;
@@ -230,25 +265,14 @@ __device__ void polar_rotation(const double A[3][3], float R_[9]) {
         }
 }
 
-// out[0..2] = cm, out[3..11] = R.  mode 0: cm only -> rigid_rest_cm[object_id]
-// (sph_base.py:87-89, NaN = 0/0 for static bodies like the reference);
-// mode 1: cm + polar(A) (sph_base.py:212-215).
-__global__ void k_rigid_finalize(DevView d, const double* __restrict__ accum, int object_id, int mode,
-                                 float* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    // f32 division like the reference's cm /= sum_m
-    const float sum_m = (float)accum[0];
-    const float cm[3] = {(float)accum[1] / sum_m, (float)accum[2] / sum_m, (float)accum[3] / sum_m};
-    out[0] = cm[0]; out[1] = cm[1]; out[2] = cm[2];
-    if (mode == 0) {
-        d.rigid_rest_cm[3 * object_id + 0] = cm[0];
-        d.rigid_rest_cm[3 * object_id + 1] = cm[1];
-        d.rigid_rest_cm[3 * object_id + 2] = cm[2];
-        return;
-    }
+// cm (and the polar rotation) from the summed partials; one lane per block computes them into LDS
+__device__ __forceinline__ void rigid_cm_R(const double* tot, bool want_R, float* cmR /*[12] in LDS*/) {
+    const float sum_m = (float)tot[0];  // f32 division like the reference's cm /= sum_m (0/0 = NaN for static bodies)
+    cmR[0] = (float)tot[1] / sum_m; cmR[1] = (float)tot[2] / sum_m; cmR[2] = (float)tot[3] / sum_m;
+    if (!want_R) return;
     double A[3][3];
     for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) A[i][j] = (double)(float)accum[4 + 3 * i + j];
+        for (int j = 0; j < 3; ++j) A[i][j] = (double)(float)tot[4 + 3 * i + j];
     float R[9];
     polar_rotation(A, R);
     bool all_small = true;
@@ -258,12 +282,39 @@ __global__ void k_rigid_finalize(DevView d, const double* __restrict__ accum, in
         for (int i = 0; i < 9; ++i) R[i] = 0.0f;
         R[0] = R[4] = R[8] = 1.0f;
     }
-    for (int i = 0; i < 9; ++i) out[3 + i] = R[i];
+    for (int i = 0; i < 9; ++i) cmR[3 + i] = R[i];
 }
 
-// sph_base.py:217-221: x = cm + R (x_0 - cm_rest)
+// mode 0: cm -> rigid_rest_cm[object_id] (sph_base.py:87-89) and out[0..2]; mode 2: cm -> out only
+__global__ __launch_bounds__(64) void k_rigid_cm_only(DevView d, const double* __restrict__ part, int nblk, int object_id,
+                                                      int mode, float* __restrict__ out) {
+    __shared__ double s_tmp[16];
+    __shared__ float cmR[12];
+    double tot[4];
+    sum_partials(part, nblk, 0, 4, tot, s_tmp);
+    if (threadIdx.x == 0) {
+        rigid_cm_R(tot, false, cmR);
+        for (int k = 0; k < 3; ++k) {
+            out[k] = cmR[k];
+            if (mode == 0) d.rigid_rest_cm[3 * object_id + k] = cmR[k];
+        }
+    }
+}
+
+// sph_base.py:212-221: R = polar(A) (+ identity fallback), x = cm + R (x_0 - cm_rest).  Every block derives cm and R
+// from the partials itself (a 3x3 f64 Jacobi is cheaper than another launch); block 0 also publishes them.
 __global__ __launch_bounds__(TPB) void k_rigid_apply(DevView d, const int* __restrict__ list, int n, int object_id,
-                                                     const float* __restrict__ cmR) {
+                                                     const double* __restrict__ part, int nblk, float* __restrict__ out) {
+    __shared__ double s_tmp[16];
+    __shared__ float cmR[12];
+    double tot[13];
+    sum_partials(part, nblk, 0, 13, tot, s_tmp);
+    if (threadIdx.x == 0) {
+        rigid_cm_R(tot, true, cmR);
+        if (blockIdx.x == 0)
+            for (int k = 0; k < 12; ++k) out[k] = cmR[k];
+    }
+    __syncthreads();
     const int tix = blockIdx.x * TPB + threadIdx.x;
     if (tix >= n) return;
     const int i = list[tix];
@@ -401,33 +452,29 @@ int sphk_enforce_boundary(SphContext* c, int particle_type) {
 // cm of object -> rigid_R[0..2] (and rigid_rest_cm[object] when to_rest)
 int sphk_rigid_com(SphContext* c, int object_id, bool to_rest) {
     DevView d = sph_view(c);
-    SPH_HIP(c, hipMemsetAsync(c->rigid_accum, 0, sizeof(double) * 16, c->stream));
-    if (c->n_dyn_host > 0) {
-        hipLaunchKernelGGL(k_rigid_sum, dim3((c->n_dyn_host + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, c->dyn_list,
-                           c->n_dyn_host, object_id, c->rigid_accum);
-        SPH_LAUNCH_CHECK(c);
-    }
-    if (to_rest) {
-        hipLaunchKernelGGL(k_rigid_finalize, dim3(1), dim3(64), 0, c->stream, d, c->rigid_accum, object_id, 0,
-                           c->rigid_R);
-        SPH_LAUNCH_CHECK(c);
-    }
+    const int n = c->n_dyn_host > 0 ? c->n_dyn_host : 0;
+    const int nb = n > 0 ? (n + TPB - 1) / TPB : 1;
+    if (nb > c->rigid_part_blocks) return sph_fail(c, SPH_E_NOMEM, "rigid partial-sum buffer too small");
+    // n == 0 (no dynamic particle, e.g. the rest cm of a static body): one block of zeros -> 0/0 = NaN like the reference
+    hipLaunchKernelGGL(k_rigid_sum, dim3(nb), dim3(TPB), 0, c->stream, d, c->dyn_list, n, object_id, c->rigid_part);
+    SPH_LAUNCH_CHECK(c);
+    hipLaunchKernelGGL(k_rigid_cm_only, dim3(1), dim3(64), 0, c->stream, d, c->rigid_part, nb, object_id, to_rest ? 0 : 2,
+                       c->rigid_R);
+    SPH_LAUNCH_CHECK(c);
     return 0;
 }
 
-// solve_constraints (sph_base.py:200-222) without any host round trip
+// solve_constraints (sph_base.py:200-222) without any host round trip: 3 launches, no atomics
 int sphk_rigid_solve(SphContext* c, int object_id) {
     if (c->n_dyn_host <= 0) return 0;
-    int rc = sphk_rigid_com(c, object_id, false);
-    if (rc) return rc;
     DevView d = sph_view(c);
-    const int nb = (c->n_dyn_host + TPB - 1) / TPB;
-    hipLaunchKernelGGL(k_rigid_A, dim3(nb), dim3(TPB), 0, c->stream, d, c->dyn_list, c->n_dyn_host, object_id,
-                       c->rigid_accum);
+    const int n = c->n_dyn_host, nb = (n + TPB - 1) / TPB;
+    if (nb > c->rigid_part_blocks) return sph_fail(c, SPH_E_NOMEM, "rigid partial-sum buffer too small");
+    hipLaunchKernelGGL(k_rigid_sum, dim3(nb), dim3(TPB), 0, c->stream, d, c->dyn_list, n, object_id, c->rigid_part);
     SPH_LAUNCH_CHECK(c);
-    hipLaunchKernelGGL(k_rigid_finalize, dim3(1), dim3(64), 0, c->stream, d, c->rigid_accum, object_id, 1, c->rigid_R);
+    hipLaunchKernelGGL(k_rigid_A, dim3(nb), dim3(TPB), 0, c->stream, d, c->dyn_list, n, object_id, c->rigid_part, nb);
     SPH_LAUNCH_CHECK(c);
-    hipLaunchKernelGGL(k_rigid_apply, dim3(nb), dim3(TPB), 0, c->stream, d, c->dyn_list, c->n_dyn_host, object_id,
+    hipLaunchKernelGGL(k_rigid_apply, dim3(nb), dim3(TPB), 0, c->stream, d, c->dyn_list, n, object_id, c->rigid_part, nb,
                        c->rigid_R);
     SPH_LAUNCH_CHECK(c);
     return 0;

@@ -88,7 +88,8 @@ struct SphContext {
     int* dyn_list;     // [cap] sorted-order indices of dynamic rigid particles
     int* dyn_count;    // device counter
     int n_dyn_host;    // number of dynamic rigid particles (constant; counted at upload)
-    double* rigid_accum;  // [16] scratch: sum m, sum m x[3], A[9]
+    double* rigid_part;   // [rigid_part_blocks][16] per-block partial sums of the shape-matching reductions
+    int rigid_part_blocks;
     float* rigid_R;    // [12] cm[3] + R[9]
     void* stage;       // upload/download staging, cap*16 bytes (>= G*4)
     size_t stage_bytes;

@@ -224,6 +224,21 @@ int32_t sph_sort(SphContext* ctx);
  * fluid walls (the slab driver sorts and exchanges halos itself). */
 int32_t sph_sweeps(SphContext* ctx);
 
+/* ---- shape matching across slabs (sph_base.py:182-222 with the sums split over ranks) ----
+ * A body's particles may live on several ranks.  Each rank adds up ITS OWN particles of `object_id` (indices
+ * [first, first+count) of the current order = its owned range), the 16 sums of all ranks are added (one
+ * all-reduce of 16 doubles), and every rank moves all local particles of the body -- ghosts included -- with the
+ * same cm and rotation.  sums (DEVICE pointers, doubles): [0] sum m, [1..3] sum m x, [4..6] sum m q,
+ * [7..15] sum m x (x) q row-major, with m = m_V0 * density, q = x_0 - rigid_rest_cm[object]; so
+ * A = sum m (x - cm)(x) q = [7..15] - cm (x) [4..6] exactly as sph_base.py:206-210.
+ * sph_rigid_partial_sums enqueues on the context's stream (sph_sync before handing the buffer to the
+ * communication library).  sph_rigid_apply_sums: mode 0 = rest centre of mass (sph_base.py:87-89), mode 1 =
+ * solve_constraints (cm, polar rotation, x = cm + R q).  x_0 lives in a persistent-id-indexed table; ranks that
+ * can receive a body's particles later load the whole body's rest positions with sph_upload_rest_positions. */
+int32_t sph_rigid_partial_sums(SphContext* ctx, int32_t object_id, int32_t first, int32_t count, double* dev_sums16);
+int32_t sph_rigid_apply_sums(SphContext* ctx, int32_t object_id, const double* dev_sums16, int32_t mode);
+int32_t sph_upload_rest_positions(SphContext* ctx, const int32_t* pid, const float* x0, int32_t n);
+
 #ifdef __cplusplus
 }
 #endif

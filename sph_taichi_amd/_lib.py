@@ -92,6 +92,9 @@ SYMBOLS = [
     ("sph_slab_density", C.c_int32, [_ctx]),
     ("sph_sort", C.c_int32, [_ctx]),
     ("sph_sweeps", C.c_int32, [_ctx]),
+    ("sph_rigid_partial_sums", C.c_int32, [_ctx, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    ("sph_rigid_apply_sums", C.c_int32, [_ctx, C.c_int32, C.c_void_p, C.c_int32]),
+    ("sph_upload_rest_positions", C.c_int32, [_ctx, C.c_void_p, C.c_void_p, C.c_int32]),
 ]
 
 _LIB = None

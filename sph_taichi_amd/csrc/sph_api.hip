@@ -576,6 +576,7 @@ int32_t sph_select_range(SphContext* c, int32_t first, int32_t count) {
 
 int32_t sph_truncate(SphContext* c, int32_t n) {
     if (!c || n < 0 || n > c->N) return sph_fail(c, SPH_E_INVALID, "sph_truncate: out of range");
+    if (n != c->N && !c->opt_no_dynamic) c->n_dyn_host = -1;  // the sort's list skipped the dropped strays: recount
     c->N = n;
     return 0;
 }
@@ -689,6 +690,40 @@ int32_t sph_slab_density(SphContext* c) {
     rc = rc ? rc : refresh_dyn(c);
     if (!rc && c->n_dyn_host > 0) rc = sphk_gather(c, GM_BVOL_DYNAMIC);
     return rc ? rc : sphk_gather(c, GM_DENSITY_EOS);
+}
+
+int32_t sph_rigid_partial_sums(SphContext* c, int32_t object_id, int32_t first, int32_t count, double* dev_sums16) {
+    ENTER(c);
+    if (object_id < 0 || object_id >= c->p.n_objects || !dev_sums16 || first < 0 || count < 0 || first + count > c->N)
+        return sph_fail(c, SPH_E_INVALID, "sph_rigid_partial_sums: bad arguments");
+    int rc = refresh_dyn(c);
+    return rc ? rc : sphk_rigid_partial16(c, object_id, first, count, dev_sums16);
+}
+
+int32_t sph_rigid_apply_sums(SphContext* c, int32_t object_id, const double* dev_sums16, int32_t mode) {
+    ENTER(c);
+    if (object_id < 0 || object_id >= c->p.n_objects || !dev_sums16 || (mode != 0 && mode != 1))
+        return sph_fail(c, SPH_E_INVALID, "sph_rigid_apply_sums: bad arguments");
+    int rc = refresh_dyn(c);
+    return rc ? rc : sphk_rigid_apply16(c, object_id, dev_sums16, mode);
+}
+
+int32_t sph_upload_rest_positions(SphContext* c, const int32_t* pid, const float* x0, int32_t n) {
+    ENTER(c);
+    if (n < 0 || (n > 0 && (!pid || !x0))) return sph_fail(c, SPH_E_INVALID, "sph_upload_rest_positions: bad arguments");
+    // staged in chunks through the upload buffer: [pid i32 | x0 3 f32] = 16 bytes per entry
+    const int chunk = (int)(c->stage_bytes / 16);
+    for (int done = 0; done < n; done += chunk) {
+        const int m = n - done < chunk ? n - done : chunk;
+        int* dpid = (int*)c->stage;
+        float* dx0 = (float*)((char*)c->stage + (size_t)m * 4);
+        SPH_HIP(c, hipMemcpyAsync(dpid, pid + done, (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
+        SPH_HIP(c, hipMemcpyAsync(dx0, x0 + 3 * (size_t)done, (size_t)m * 12, hipMemcpyHostToDevice, c->stream));
+        int rc = sphk_scatter_rest(c, dpid, dx0, m);
+        if (rc) return rc;
+        SPH_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
 }
 
 int32_t sph_slab_wait_pack(SphContext* c) {

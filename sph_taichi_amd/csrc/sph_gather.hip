@@ -300,11 +300,12 @@ __global__ __launch_bounds__(TPB) void k_gather_bvol_split(DevView d, const int*
     const int i = live ? list[tix] : 0;
     const float4 A = d.xm[i];
     const int fl = __float_as_int(d.vf[i].w);
-    const bool g = live && target_gathers<MODE>(fl);
+    const int c = d.key[i];
+    const int cz = c % d.nz, cy = (c / d.nz) % d.ny, cx = c / (d.nz * d.ny);
+    // slab rank: the outermost ghost layer has no neighbours beyond it; its volumes arrive with the owner's records
+    const bool g = live && target_gathers<MODE>(fl) && !(d.drop_outside && (cx < 1 || cx >= d.nx - 1));
     float sum = 0.0f;
     if (g && r < 9) {
-        const int c = d.key[i];
-        const int cz = c % d.nz, cy = (c / d.nz) % d.ny, cx = c / (d.nz * d.ny);
         const int nx = cx + r / 3 - 1, ny = cy + r % 3 - 1;
         if (nx >= 0 && nx < d.nx && ny >= 0 && ny < d.ny) {
             const int zlo = cz > 0 ? cz - 1 : 0, zhi = cz < d.nz - 1 ? cz + 1 : d.nz - 1;

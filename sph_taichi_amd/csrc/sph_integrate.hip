@@ -335,6 +335,94 @@ __global__ __launch_bounds__(TPB) void k_rigid_apply(DevView d, const int* __res
     d.xm[i] = xm;
 }
 
+// ---- the same solve with the sums split over slabs (include/sph_hip.h: sph_rigid_partial_sums) ----
+// per-block partials of the 16 one-pass sums over the dynamic-rigid particles of `object_id` with index in [first,last)
+__global__ __launch_bounds__(TPB) void k_rigid_sum16(DevView d, const int* __restrict__ list, int n, int object_id,
+                                                     int first, int last, double* __restrict__ part) {
+    const int tix = blockIdx.x * TPB + threadIdx.x;
+    double s[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (tix < n) {
+        const int i = list[tix];
+        const int fl = __float_as_int(d.vf[i].w);
+        if (i >= first && i < last && sph_is_dynamic_rigid(fl) && sph_flags_object(fl) == object_id) {
+            const float4 xm = d.xm[i];
+            const float4 aux = d.aux[i];
+            const int pid = __float_as_int(aux.w);
+            const float* rc = &d.rigid_rest_cm[3 * object_id];
+            const float mass = d.m_V0 * aux.y;
+            const float x[3] = {xm.x, xm.y, xm.z};
+            const float q[3] = {d.x0_cold[3 * pid] - rc[0], d.x0_cold[3 * pid + 1] - rc[1],
+                                d.x0_cold[3 * pid + 2] - rc[2]};
+            s[0] = mass;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                s[1 + a] = (double)(mass * x[a]);  // same f32 product as k_rigid_sum
+                s[4 + a] = (double)mass * (double)q[a];
+#pragma unroll
+                for (int b = 0; b < 3; ++b) s[7 + 3 * a + b] = (double)mass * (double)x[a] * (double)q[b];
+            }
+        }
+    }
+    block_store_partials<16>(s, part, 0);
+}
+
+__global__ __launch_bounds__(64) void k_rigid_total16(const double* __restrict__ part, int nblk, double* __restrict__ out) {
+    __shared__ double s_tmp[16];
+    double tot[16];
+    sum_partials(part, nblk, 0, 16, tot, s_tmp);
+    if (threadIdx.x < 16) out[threadIdx.x] = nblk > 0 ? s_tmp[threadIdx.x] : 0.0;
+}
+
+// mode 0: rest cm; mode 1: cm + polar rotation + goal positions for every local particle of the object
+__global__ __launch_bounds__(TPB) void k_rigid_apply_sums(DevView d, const int* __restrict__ list, int n, int object_id,
+                                                          const double* __restrict__ sums, int mode,
+                                                          float* __restrict__ out) {
+    __shared__ float cmR[12];
+    if (threadIdx.x == 0) {
+        double tot[13];
+        for (int k = 0; k < 4; ++k) tot[k] = sums[k];
+        const float sum_m = (float)tot[0];
+        const double cm[3] = {(double)((float)tot[1] / sum_m), (double)((float)tot[2] / sum_m),
+                              (double)((float)tot[3] / sum_m)};
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) tot[4 + 3 * a + b] = sums[7 + 3 * a + b] - cm[a] * sums[4 + b];
+        rigid_cm_R(tot, mode == 1, cmR);
+        if (blockIdx.x == 0) {
+            for (int k = 0; k < (mode == 1 ? 12 : 3); ++k) out[k] = cmR[k];
+            if (mode == 0)
+                for (int k = 0; k < 3; ++k) d.rigid_rest_cm[3 * object_id + k] = cmR[k];
+        }
+    }
+    __syncthreads();
+    if (mode != 1) return;
+    const int tix = blockIdx.x * TPB + threadIdx.x;
+    if (tix >= n) return;
+    const int i = list[tix];
+    const int fl = __float_as_int(d.vf[i].w);
+    if (!(sph_is_dynamic_rigid(fl) && sph_flags_object(fl) == object_id)) return;
+    const int pid = __float_as_int(d.aux[i].w);
+    const float* rc = &d.rigid_rest_cm[3 * object_id];
+    const float q[3] = {d.x0_cold[3 * pid] - rc[0], d.x0_cold[3 * pid + 1] - rc[1], d.x0_cold[3 * pid + 2] - rc[2]};
+    float4 xm = d.xm[i];
+    float x[3] = {xm.x, xm.y, xm.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float goal = cmR[a] + (cmR[3 + 3 * a] * q[0] + cmR[3 + 3 * a + 1] * q[1] + cmR[3 + 3 * a + 2] * q[2]);
+        x[a] += (goal - x[a]) * 1.0f;
+    }
+    xm.x = x[0]; xm.y = x[1]; xm.z = x[2];
+    d.xm[i] = xm;
+}
+
+__global__ __launch_bounds__(TPB) void k_scatter_rest(float* __restrict__ x0_cold, const int* __restrict__ pid,
+                                                      const float* __restrict__ x0, int n, int cap) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const int p = pid[i];
+    if (p < 0 || p >= cap) return;
+    for (int k = 0; k < 3; ++k) x0_cold[3 * p + k] = x0[3 * i + k];
+}
+
 // list of dynamic rigid particles in the CURRENT order (used before the first sort)
 __global__ __launch_bounds__(TPB) void k_build_dyn_list(DevView d, int* __restrict__ list, int* __restrict__ count) {
     const int i = blockIdx.x * TPB + threadIdx.x;
@@ -512,5 +600,37 @@ int sphk_build_dyn_list(SphContext* c) {
                            c->dyn_count);
         SPH_LAUNCH_CHECK(c);
     }
+    return 0;
+}
+
+int sphk_rigid_partial16(SphContext* c, int object_id, int first, int count, double* out) {
+    DevView d = sph_view(c);
+    const int n = c->n_dyn_host;
+    const int nb = n > 0 ? (n + TPB - 1) / TPB : 0;
+    if (nb > c->rigid_part_blocks) return sph_fail(c, SPH_E_NOMEM, "rigid partial-sum buffer too small");
+    if (nb > 0) {
+        hipLaunchKernelGGL(k_rigid_sum16, dim3(nb), dim3(TPB), 0, c->stream, d, c->dyn_list, n, object_id, first,
+                           first + count, c->rigid_part);
+        SPH_LAUNCH_CHECK(c);
+    }
+    hipLaunchKernelGGL(k_rigid_total16, dim3(1), dim3(64), 0, c->stream, c->rigid_part, nb, out);
+    SPH_LAUNCH_CHECK(c);
+    return 0;
+}
+
+int sphk_rigid_apply16(SphContext* c, int object_id, const double* sums, int mode) {
+    DevView d = sph_view(c);
+    const int n = c->n_dyn_host;
+    const int nb = (mode == 1 && n > 0) ? (n + TPB - 1) / TPB : 1;
+    hipLaunchKernelGGL(k_rigid_apply_sums, dim3(nb), dim3(TPB), 0, c->stream, d, c->dyn_list, n, object_id, sums, mode,
+                       c->rigid_R);
+    SPH_LAUNCH_CHECK(c);
+    return 0;
+}
+
+int sphk_scatter_rest(SphContext* c, const int* pid_dev, const float* x0_dev, int n) {
+    hipLaunchKernelGGL(k_scatter_rest, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, c->stream, c->x0_cold, pid_dev, x0_dev, n,
+                       c->cold_cap);
+    SPH_LAUNCH_CHECK(c);
     return 0;
 }

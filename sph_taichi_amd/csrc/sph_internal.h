@@ -122,6 +122,9 @@ int sph_fail(SphContext* c, int code, const char* what);
 int sphk_hash_histogram(SphContext* c);
 int sphk_scan(SphContext* c);
 int sphk_sort_scatter(SphContext* c, bool sort_acc);
+int sphk_rigid_partial16(SphContext* c, int object_id, int first, int count, double* out);
+int sphk_rigid_apply16(SphContext* c, int object_id, const double* sums, int mode);
+int sphk_scatter_rest(SphContext* c, const int* pid_dev, const float* x0_dev, int n);
 int sphk_gather(SphContext* c, int mode);
 int sphk_gather_layers(SphContext* c, int mode, int lo, int hi, int lo2, int hi2);  // brick sweep, targets in x layers [lo,hi) u [lo2,hi2)
 int sphk_pack_advected(SphContext* c, int first, int count, void* dst);

@@ -32,9 +32,17 @@ ROCm, "gloo" for the CPU tests) and `LocalTransport` (several logical ranks in o
 process on one GPU -- how the slab logic is verified against the single-domain run
 where only one GPU is available).
 
-Not yet supported in slab mode: dynamic rigid bodies (shape matching needs an
-all-reduce of 13 sums per body; sph_sweeps refuses), x_0/color of migrated
-particles.
+Dynamic solids.  Scenes with dynamic RigidBlocks / RigidBodies use HALO = 3: the
+moving boundary volumes (sph_base.py:106-113) of ghost layers 1..2 are then
+recomputed locally from complete neighbourhoods, exactly as the owner does.
+Shape-matched RigidBodies (sph_base.py:200-260) may straddle cuts: after the
+advect every rank adds up 16 sums over ITS OWN particles of the body, one
+all-reduce (16 doubles) gives every rank the same cm and rotation, and each rank
+moves all its local copies; the halo exchange then follows the solve, so for
+these scenes it is not hidden behind the interior force sweep.  Every rank
+holds the rest positions of all dynamic bodies (a few 10^4 rows, keyed by
+persistent id).  Not carried across ranks: `color`, and `x_0` of anything but
+dynamic bodies (neither is read by the solver).
 """
 from __future__ import annotations
 
@@ -47,7 +55,8 @@ from . import _lib, scene as _scene
 from .config_builder import SimConfig
 from .particle_system import ParticleSystem
 
-HALO = 2
+HALO = 2            # fluid + static solids; scenes with dynamic solids use HALO_DYNAMIC
+HALO_DYNAMIC = 3
 RECORD_BYTES = 48
 
 
@@ -139,60 +148,82 @@ class TorchTransport:
                     bufs[p][: n_in[p] * RECORD_BYTES].copy_(bufs[(p, "stage")])
         return (bufs.get(left), n_in.get(left, 0), bufs.get(right), n_in.get(right, 0))
 
+    def all_reduce_sum(self, t):
+        """In-place sum over ranks of a small device tensor (the 16 shape-matching sums of one body)."""
+        if self.cpu_staging:
+            h = t.cpu()
+            self.dist.all_reduce(h)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t)
+        if self.torch.cuda.is_available() and t.is_cuda:
+            self.torch.cuda.current_stream().synchronize()   # consumed on the context's stream
+        return t
+
 
 class SlabSolver:
     """One rank of the slab-decomposed WCSPH solver."""
 
     def __init__(self, scene_dict, rank, world, device=0, cuts=None, capacity_factor=1.5, use_torch_stream=False,
-                 gather_impl=1, brick_shape=0):
+                 gather_impl=1, brick_shape=0, scene_dir=None):
         import torch
         self.torch = torch
         self.rank, self.world = rank, world
         cfg = SimConfig(config=copy.deepcopy(scene_dict))
-        if cfg.get_rigid_bodies():
-            raise NotImplementedError("slab mode: RigidBodies are not supported yet")
         geom = _scene.Geometry(cfg)
         self.nx_global = int(geom.grid_num[0])
+        dyn_blocks = [b for b in cfg.get_rigid_blocks() if b.get("isDynamic")]
+        dyn_bodies = [b for b in cfg.get_rigid_bodies() if b.get("isDynamic")]
+        self.has_dynamic = bool(dyn_blocks or dyn_bodies)
+        self.halo = halo = HALO_DYNAMIC if self.has_dynamic else HALO
+        hist = _scene.x_layer_histogram(cfg, base_dir=scene_dir)
         if cuts is None:
-            cuts = _scene.slab_cuts(_scene.x_layer_histogram(cfg), world, min_width=HALO + 1)
+            cuts = _scene.slab_cuts(hist, world, min_width=halo + 1)
         self.cuts = list(cuts)
         self.x_lo, self.x_hi = self.cuts[rank], self.cuts[rank + 1]
-        if self.x_hi - self.x_lo < HALO + 1:
-            raise ValueError(f"slab {rank} is {self.x_hi - self.x_lo} layers wide; need >= {HALO + 1}")
-        hist = _scene.x_layer_histogram(cfg)
+        if self.x_hi - self.x_lo < halo + 1:
+            raise ValueError(f"slab {rank} is {self.x_hi - self.x_lo} layers wide; need >= {halo + 1}")
         own = int(hist[self.x_lo:self.x_hi].sum())
         per_layer = int(hist.max())
-        capacity = int(capacity_factor * own) + (2 * HALO + 2) * 2 * per_layer + 1024
+        capacity = int(capacity_factor * own) + (2 * halo + 2) * 2 * per_layer + 1024
         self.device = device
         self.tdev = torch.device("cuda", device)
         stream = torch.cuda.current_stream(self.tdev).cuda_stream if use_torch_stream else None
-        self.ps = ParticleSystem(cfg, device=device, stream=stream,
-                                 slab=dict(x_lo=self.x_lo, x_hi=self.x_hi, halo=HALO, capacity=capacity))
+        self.ps = ParticleSystem(cfg, device=device, stream=stream, scene_dir=scene_dir,
+                                 slab=dict(x_lo=self.x_lo, x_hi=self.x_hi, halo=halo, capacity=capacity))
         self.ps.set_option(_lib.OPT_GATHER_IMPL, gather_impl)
         self.ps.set_option(_lib.OPT_BRICK_SHAPE, brick_shape)
-        dyn_blocks = [b for b in cfg.get_rigid_blocks() if b.get("isDynamic")]
-        self.ps.set_option(_lib.OPT_NO_DYNAMIC_SOLIDS, 0 if dyn_blocks else 1)
+        self.ps.set_option(_lib.OPT_NO_DYNAMIC_SOLIDS, 0 if self.has_dynamic else 1)
         self.ps.set_option(_lib.OPT_SLAB_DROP_OUTSIDE, 1)
-        nxl = self.x_hi - self.x_lo + 2 * HALO
+        nxl = self.x_hi - self.x_lo + 2 * halo
         # targets: density on owned + ghost layer 1 (its rho/p feed the owned forces); forces on owned only,
         # or also on ghost layer 1 when dynamic solids exist (their owner accumulates the coupling reaction
         # from its ghost fluid neighbours)
-        f_lo, f_hi = (HALO - 1, nxl - HALO + 1) if dyn_blocks else (HALO, nxl - HALO)
-        self.ps._call("sph_set_target_layers", HALO - 1, nxl - HALO + 1, f_lo, f_hi)
+        f_lo, f_hi = (halo - 1, nxl - halo + 1) if self.has_dynamic else (halo, nxl - halo)
+        self.ps._call("sph_set_target_layers", halo - 1, nxl - halo + 1, f_lo, f_hi)
         self.solver = self.ps.build_solver()
-        self.nx_local = self.x_hi - self.x_lo + 2 * HALO
+        self.nx_local = nxl
         self.capacity = capacity
-        nbuf = (HALO + 2) * 2 * per_layer * RECORD_BYTES + 4096
+        nbuf = (halo + 2) * 2 * per_layer * RECORD_BYTES + 4096
         self.send_buf = {side: torch.empty(nbuf, dtype=torch.uint8, device=self.tdev) for side in ("L", "R")}
         self.recv_buf = {side: torch.empty(nbuf, dtype=torch.uint8, device=self.tdev) for side in ("L", "R")}
         self.nbuf = nbuf
         self.owned_range = None     # (first, count) of the owned particles in the current order
         self.off = None
         self._need_density = True
-        self.has_dynamic = bool(dyn_blocks)
         self.transport = None
         self.has_left, self.has_right = rank > 0, rank < world - 1
         self.stats = {"sent": 0, "received": 0}
+        # shape-matched bodies (sph_base.py:247-260 iterates object_id_rigid_body; only dynamic ones move)
+        sc = self.ps._scene
+        self.dynamic_bodies = sorted(sc.dynamic_rigid_ids)
+        self.sums = torch.zeros(16, dtype=torch.float64, device=self.tdev)
+        for oid in self.dynamic_bodies:
+            body = sc.object_collection[oid]
+            rest = np.ascontiguousarray(np.asarray(body["voxelizedPoints"], dtype=np.float32))
+            pid = np.ascontiguousarray(body["pidStart"] + np.arange(rest.shape[0], dtype=np.int32), dtype=np.int32)
+            self.ps._call("sph_upload_rest_positions", pid.ctypes.data_as(C.c_void_p),
+                          rest.ctypes.data_as(C.c_void_p), int(rest.shape[0]))
 
     # -- helpers ------------------------------------------------------------
     def _offsets(self, layers):
@@ -210,7 +241,7 @@ class SlabSolver:
 
     # -- step phases ---------------------------------------------------------------
     # `self.off` holds, for the CURRENT order (the one the last sort produced), the record offsets of the layer
-    # boundaries [HALO, 2*HALO+1, nx-2*HALO-1, nx-HALO]: the ranges to send and the owned range are known on
+    # boundaries [H, 2*H+1, nx-2*H-1, nx-H]: the ranges to send and the owned range are known on
     # the host.  Per step:
     #   phase_forces : force sweep of the boundary layers, halo packers (records as they will be after this
     #                  step's advect), event; then interior force sweep + in-place advect keep the GPU busy
@@ -239,28 +270,59 @@ class SlabSolver:
         self.stats["sent"] += nL + nR
         return self.send_buf["L"], nL, self.send_buf["R"], nR
 
-    def phase_forces(self):
+    def phase_forces(self, pack=True):
+        """pack=False (scenes with shape-matched bodies): all force sweeps + advect, nothing packed yet."""
         ps = self.ps
+        H = self.halo
         if self._need_density:
             ps._call("sph_slab_density")
             self._need_density = False
-        nL, nR = self.next_counts()
+        nL, nR = self.next_counts() if pack else (0, 0)
         self._ensure_send_bufs(nL, nR)
         nx = self.nx_local
         extra = 1 if self.has_dynamic else 0      # coupling reactions on boundary solids come from one layer further in
-        ps._call("sph_slab_forces", HALO, 2 * HALO + 1 + extra, nx - 2 * HALO - 1 - extra, nx - HALO,
+        ps._call("sph_slab_forces", H, 2 * H + 1 + extra, nx - 2 * H - 1 - extra, nx - H,
                  self.off[0], nL, C.c_void_p(self.send_buf["L"].data_ptr()),
                  self.off[2], nR, C.c_void_p(self.send_buf["R"].data_ptr()))
         ps._call("sph_slab_wait_pack")
         self.stats["sent"] += nL + nR
         return self.send_buf["L"], nL, self.send_buf["R"], nR
 
+    def pack_now(self):
+        """Pack the boundary layers as they are now (after advect + rigid solve); synchronises."""
+        nL, nR = self.next_counts()
+        self._ensure_send_bufs(nL, nR)
+        self.ps._call("sph_slab_pack", self.off[0], nL, C.c_void_p(self.send_buf["L"].data_ptr()),
+                      self.off[2], nR, C.c_void_p(self.send_buf["R"].data_ptr()))
+        self.stats["sent"] += nL + nR
+        return self.send_buf["L"], nL, self.send_buf["R"], nR
+
+    def rigid_partial(self, oid):
+        """This rank's 16 shape-matching sums of body `oid` (device tensor, ready for the all-reduce)."""
+        first, count = self.owned_range
+        self.ps._call("sph_rigid_partial_sums", int(oid), first, count, C.c_void_p(self.sums.data_ptr()))
+        self.ps.sync()
+        return self.sums
+
+    def rigid_apply(self, oid, mode):
+        """mode 0: rest centre of mass (sph_base.py:87-89); 1: solve_constraints + enforce_boundary_3D(solid)
+        (sph_base.py:247-260)."""
+        self.ps._call("sph_rigid_apply_sums", int(oid), C.c_void_p(self.sums.data_ptr()), int(mode))
+        if mode == 1:
+            self.ps._call("sph_enforce_boundary_3D", _scene.MATERIAL_SOLID)
+
+    def solve_rigid_bodies(self, mode=1):
+        for oid in self.dynamic_bodies:
+            self.transport.all_reduce_sum(self.rigid_partial(oid))
+            self.rigid_apply(oid, mode)
+
     def phase_advance(self, recv_left, n_left, recv_right, n_right, density=True):
         ps = self.ps
+        H = self.halo
         o = self.off
         self.stats["received"] += n_left + n_right
         nx = self.nx_local
-        layers = (C.c_int32 * 5)(HALO, 2 * HALO + 1, nx - 2 * HALO - 1, nx - HALO, nx)
+        layers = (C.c_int32 * 5)(H, 2 * H + 1, nx - 2 * H - 1, nx - H, nx)
         ps._call("sph_slab_advance", o[0], o[3] - o[0],
                  C.c_void_p(recv_left.data_ptr()) if n_left > 0 else None, n_left,
                  C.c_void_p(recv_right.data_ptr()) if n_right > 0 else None, n_right, layers, 5, 2 if density else 0)
@@ -271,7 +333,8 @@ class SlabSolver:
 
     def _read_offsets(self, begin):
         nx = self.nx_local
-        layers = [HALO, 2 * HALO + 1, nx - 2 * HALO - 1, nx - HALO, nx]
+        H = self.halo
+        layers = [H, 2 * H + 1, nx - 2 * H - 1, nx - H, nx]
         if begin:
             self.ps._call("sph_layer_offsets_begin", (C.c_int32 * 5)(*layers), 5)
         out = (C.c_int32 * 5)()
@@ -291,7 +354,13 @@ class SlabSolver:
 
     def step(self, n=1):
         for _ in range(n):
-            rL, mL, rR, mR = self._exchange(*self.phase_forces())
+            if self.dynamic_bodies:
+                self.phase_forces(pack=False)
+                self.solve_rigid_bodies()
+                sent = self.pack_now()
+            else:
+                sent = self.phase_forces()
+            rL, mL, rR, mR = self._exchange(*sent)
             self.phase_advance(rL, mL, rR, mR)
 
     def initialize(self):
@@ -300,7 +369,11 @@ class SlabSolver:
         self.solver._push()
         rL, mL, rR, mR = self._exchange(*self.init_pack())
         self.phase_advance(rL, mL, rR, mR, density=False)
+        self.solve_rigid_bodies(mode=0)
         self.ps._call("sph_compute_boundary_volume", 0)
+        # once more, so that the ghosts carry their owners' boundary volumes into the first step
+        rL, mL, rR, mR = self._exchange(*self.init_pack())
+        self.phase_advance(rL, mL, rR, mR, density=False)
 
     # -- inspection (tests) ----------------------------------------------------
     def owned(self, names=("pid", "x", "v")):
@@ -313,7 +386,7 @@ class SlabSolver:
 
 def run_local_slabs(solvers, n_steps, initialize=False):
     """Drive P SlabSolvers that live in ONE process (one GPU) in lock-step; a neighbour's send buffer is read
-    directly (device pointer), which is all `LocalTransport` would do."""
+    directly (device pointer) and the bodies' sums are added on the spot -- what the transports do between ranks."""
     P = len(solvers)
 
     def swap(sent):
@@ -326,18 +399,36 @@ def run_local_slabs(solvers, n_steps, initialize=False):
             out.append((rl[0], rl[1], rr[0], rr[1]))
         return out
 
+    def solve_bodies(mode):
+        for oid in solvers[0].dynamic_bodies:
+            total = sum(s.rigid_partial(oid).clone() for s in solvers)
+            for s in solvers:
+                s.sums.copy_(total)
+                s.torch.cuda.current_stream().synchronize()
+                s.rigid_apply(oid, mode)
+
+    def exchange_and_advance(sent, density):
+        for s, r in zip(solvers, swap(sent)):
+            s.phase_advance(*r, density=density)
+
     if initialize:
         for s in solvers:
             s.solver._push()
-        recv = swap([s.init_pack() for s in solvers])
-        for s, r in zip(solvers, recv):
-            s.phase_advance(*r, density=False)
+        exchange_and_advance([s.init_pack() for s in solvers], False)
+        solve_bodies(0)
+        for s in solvers:
             s.ps._call("sph_compute_boundary_volume", 0)
+        exchange_and_advance([s.init_pack() for s in solvers], False)
         return
     for _ in range(n_steps):
-        recv = swap([s.phase_forces() for s in solvers])
-        for s, r in zip(solvers, recv):
-            s.phase_advance(*r)
+        if solvers[0].dynamic_bodies:
+            for s in solvers:
+                s.phase_forces(pack=False)
+            solve_bodies(1)
+            sent = [s.pack_now() for s in solvers]
+        else:
+            sent = [s.phase_forces() for s in solvers]
+        exchange_and_advance(sent, True)
 
 
 def gather_by_pid(solvers, name, n_global):
@@ -407,7 +498,7 @@ def run_slab_bench(args, rank, world, local_rank):
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"c3p_tiled_x{world}_{246 * world}x74x96", "particles": n_global,
-                   "particles_owned_sum": int(own.item()), "cuts": s.cuts, "halo_layers": HALO,
+                   "particles_owned_sum": int(own.item()), "cuts": s.cuts, "halo_layers": s.halo,
                    "sent_records_per_step": round(s.stats["sent"] / max(args.steps + args.warmup + 1, 1), 1),
                    "backend": dist.get_backend(),
                    "parallelism": f"x-slab x{world}, 1 exchange/step over RCCL P2P"},

@@ -203,6 +203,7 @@ def build_scene(cfg, base_dir: str | None = None, verbose: bool = False, x_filte
         oid = body["objectId"]
         sc.object_id_rigid_body.add(oid)
         n = body["particleNum"]
+        body["pidStart"] = b.global_count          # persistent ids of the body: pidStart + [0, n)
         dyn = body["isDynamic"]
         vel = np.array(body["velocity"], dtype=np.float32) if dyn else np.zeros(3, dtype=np.float32)
         b.add_particles(oid, n, np.array(body["voxelizedPoints"], dtype=np.float32), np.tile(vel, (n, 1)),
@@ -233,8 +234,8 @@ def x_layer_of(xs, grid_size, nx):
     return np.clip(layer, 0, nx - 1)
 
 
-def x_layer_histogram(cfg):
-    """Particles per global x cell layer, from the block axes alone (no particle arrays)."""
+def x_layer_histogram(cfg, base_dir=None):
+    """Particles per global x cell layer, from the block axes (no particle arrays) and the bodies' voxel points."""
     g = Geometry(cfg)
     nx = int(g.grid_num[0])
     hist = np.zeros(nx, dtype=np.int64)
@@ -244,8 +245,11 @@ def x_layer_histogram(cfg):
         size = (end - start) * np.array(blk["scale"])
         axes = [np.arange(start[i], start[i] + size[i], g.particle_diameter) for i in range(3)]
         np.add.at(hist, x_layer_of(axes[0], g.grid_size, nx), len(axes[1]) * len(axes[2]))
-    if cfg.get_rigid_bodies():
-        raise NotImplementedError("x_layer_histogram: RigidBodies need the voxelised points; build the scene instead")
+    for body in cfg.get_rigid_bodies():
+        pts = body.get("voxelizedPoints")
+        if pts is None:
+            pts, _ = voxelizer.load_rigid_body(body, g.particle_diameter, base_dir or os.getcwd())
+        np.add.at(hist, x_layer_of(np.asarray(pts, dtype=np.float32)[:, 0], g.grid_size, nx), 1)
     return hist
 
 

@@ -55,6 +55,31 @@ def fluid_with_rigid_blocks(fluid_counts=(10, 10, 8), static_counts=(14, 2, 12),
     }
 
 
+def write_cube_obj(path, lo, side):
+    """Closed cube as 12 triangles (outward winding)."""
+    v = [(lo[0] + side * i, lo[1] + side * j, lo[2] + side * k) for i in (0, 1) for j in (0, 1) for k in (0, 1)]
+    quads = [(1, 2, 4, 3), (5, 7, 8, 6), (1, 5, 6, 2), (3, 4, 8, 7), (1, 3, 7, 5), (2, 6, 8, 4)]
+    with open(path, "w") as fh:
+        for p in v:
+            fh.write("v %.6f %.6f %.6f\n" % p)
+        for a, b, c, d in quads:
+            fh.write(f"f {a} {b} {c}\nf {a} {c} {d}\n")
+
+
+def fluid_with_rigid_bodies(obj_path, fluid_velocity=(0.0, -1.0, 0.0)):
+    """Two dynamic RigidBodies (voxelised 0.1 cubes, one rotated by 30 deg) dropping into a fluid block next to a
+    static body: shape matching (sph_base.py:182-260) + two-way coupling."""
+    write_cube_obj(obj_path, (0.0, 0.0, 0.0), 0.1)
+    sd = fluid_only(counts=(14, 8, 12), start=(0.1, 0.1, 0.1), velocity=fluid_velocity)
+    body = lambda oid, tr, ang, dyn, rho: {"objectId": oid, "geometryFile": obj_path, "translation": list(tr),
+                                           "rotationAxis": [0, 0, 1], "rotationAngle": ang, "scale": [1, 1, 1],
+                                           "velocity": [0.0, -2.0, 0.0], "density": rho, "color": [255, 255, 255],
+                                           "isDynamic": dyn}
+    sd["RigidBodies"] = [body(1, (0.14, 0.26, 0.14), 0, True, 600.0), body(2, (0.28, 0.27, 0.18), 30, True, 2500.0),
+                         body(3, (0.50, 0.10, 0.14), 0, False, 1000.0)]
+    return sd
+
+
 def jitter(scene, amplitude=0.1, seed=0):
     """positions += U(-a d, a d): breaks lattice ties for sort / force tests."""
     rng = np.random.default_rng(seed)

@@ -41,6 +41,9 @@ def main():
                 ok &= mR == exp and (exp == 0 or bool((rR[: exp * RECORD_BYTES] == 10 + rank + 1).all()))
             if it >= 1 and it < 4:
                 tr.start_counts(*cnt(it + 1))
+        t = torch.arange(16, dtype=torch.float64) * (rank + 1)      # the bodies' 16 shape-matching sums
+        tr.all_reduce_sum(t)
+        ok &= bool(torch.equal(t, torch.arange(16, dtype=torch.float64) * (world * (world + 1) // 2)))
         flag = torch.tensor([1 if ok else 0])
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if rank == 0:

@@ -209,27 +209,11 @@ def _scene_with_domain(sd, dom, n):
     return sd
 
 
-def _cube_obj(path, lo, size):
-    v = [(lo[0] + a * size, lo[1] + b * size, lo[2] + c * size) for a in (0, 1) for b in (0, 1) for c in (0, 1)]
-    f = [(1, 2, 4), (1, 4, 3), (5, 8, 6), (5, 7, 8), (1, 6, 2), (1, 5, 6), (3, 4, 8), (3, 8, 7), (1, 3, 7), (1, 7, 5),
-         (2, 6, 8), (2, 8, 4)]
-    with open(path, "w") as fh:
-        fh.write("".join(f"v {a} {b} {c}\n" for a, b, c in v) + "".join(f"f {a} {b} {c}\n" for a, b, c in f))
-
-
 @pytest.mark.parametrize("impl", [0, 1])
 def test_shape_matched_rigid_bodies(tmp_path, impl):
     """Two dynamic RigidBodies (voxelised cubes, one rotated) dropping into a fluid block next to a static body:
     sph_base.py:182-260 (compute_com, solve_constraints, solve_rigid_body) + two-way coupling, HIP vs oracle."""
-    obj = str(tmp_path / "cube.obj")
-    _cube_obj(obj, (0.0, 0.0, 0.0), 0.1)
-    sd = scenes.fluid_only(counts=(14, 8, 12), start=(0.1, 0.1, 0.1))
-    body = lambda oid, tr, ang, dyn, rho: {"objectId": oid, "geometryFile": obj, "translation": list(tr),
-                                           "rotationAxis": [0, 0, 1], "rotationAngle": ang, "scale": [1, 1, 1],
-                                           "velocity": [0.0, -2.0, 0.0], "density": rho, "color": [255, 255, 255],
-                                           "isDynamic": dyn}
-    sd["RigidBodies"] = [body(1, (0.14, 0.26, 0.14), 0, True, 600.0), body(2, (0.28, 0.27, 0.18), 30, True, 2500.0),
-                         body(3, (0.50, 0.10, 0.14), 0, False, 1000.0)]
+    sd = scenes.fluid_with_rigid_bodies(str(tmp_path / "cube.obj"))
     cfg, sc = scenes.build(sd)
     assert sorted(sc.dynamic_rigid_ids) == [1, 2] and sc.solid_particle_num > 400
     o = scenes.make_oracle(cfg, sc, rigid_sums_f64=True)

@@ -87,7 +87,10 @@ enum SphField {
     SPH_F_GRID_PARTICLES_NUM = 13,/* i32 [G]   particle_system.py:96  (download only) */
     SPH_F_PID = 14,               /* i32 [N]   persistent id (default: index at creation); < cold_capacity */
     SPH_F_RIGID_REST_CM = 15,     /* f32 [n_objects,3]  particle_system.py:93 */
-    SPH_F_COUNT_ = 16
+    SPH_F_DFSPH_FACTOR = 16,      /* f32 [N]   particle_system.py:116 (simulationMethod 4).  Like the reference's, */
+    SPH_F_DENSITY_ADV = 17,       /* f32 [N]   particle_system.py:117  the values are dead across steps: they are
+                                   *           NOT carried through the sort (every step recomputes them first). */
+    SPH_F_COUNT_ = 18
 };
 
 enum SphError {
@@ -238,6 +241,53 @@ int32_t sph_sweeps(SphContext* ctx);
 int32_t sph_rigid_partial_sums(SphContext* ctx, int32_t object_id, int32_t first, int32_t count, double* dev_sums16);
 int32_t sph_rigid_apply_sums(SphContext* ctx, int32_t object_id, const double* dev_sums16, int32_t mode);
 int32_t sph_upload_rest_positions(SphContext* ctx, const int32_t* pid, const float* x0, int32_t n);
+
+/* ======================================================================================
+ * DFSPH (simulationMethod 4): DFSPHSolver of /root/reference/DFSPH.py on the same neighbour
+ * machinery.  The density sweep writes every fluid particle's neighbour list once per step;
+ * all later sweeps of the step (factor, density change / advection, both Jacobi solvers,
+ * non-pressure forces) read those lists.  The solver loops run inside the library; each
+ * iteration reads one f32 back (the reference's compute_density_error does the same).
+ * ==================================================================================== */
+typedef struct SphDfsphParams {
+    int32_t enable_divergence_solver; /* DFSPH.py:12 */
+    int32_t m_max_iterations_v;       /* DFSPH.py:14 */
+    int32_t m_max_iterations;         /* DFSPH.py:15 */
+    int32_t fluid_particle_num;       /* particle_system.py:57-62: divisor of the average density error */
+    float m_eps;                      /* DFSPH.py:17 */
+    float reserved_;
+    double max_error_V;               /* DFSPH.py:19 (Python-scope floats: f64) */
+    double max_error;                 /* DFSPH.py:20 */
+} SphDfsphParams;
+
+typedef struct SphDfsphStats {
+    int32_t iterations_v;             /* what DFSPH.py:258 prints for the last divergence solve */
+    int32_t iterations;               /* what DFSPH.py:353 prints for the last pressure solve */
+    double avg_density_err_v;
+    double avg_density_err;
+    int64_t total_iterations_v;       /* solver iterations run since sph_create (incl. the unconditional first one) */
+    int64_t total_iterations;
+    int64_t steps;
+} SphDfsphStats;
+
+int32_t sph_dfsph_set_params(SphContext* ctx, const SphDfsphParams* params);
+int32_t sph_dfsph_get_stats(SphContext* ctx, SphDfsphStats* out);
+int32_t sph_dfsph_compute_densities(SphContext* ctx);              /* DFSPH.py:37-47 */
+int32_t sph_dfsph_compute_DFSPH_factor(SphContext* ctx);           /* DFSPH.py:116-154 */
+int32_t sph_dfsph_compute_density_change(SphContext* ctx);         /* DFSPH.py:157-197 */
+int32_t sph_dfsph_compute_density_adv(SphContext* ctx);            /* DFSPH.py:200-221 */
+int32_t sph_dfsph_compute_density_error(SphContext* ctx, float offset, float* out); /* DFSPH.py:224-230; synchronises */
+int32_t sph_dfsph_multiply_time_step(SphContext* ctx, float time_step);            /* DFSPH.py:233-237 on dfsph_factor */
+int32_t sph_dfsph_divergence_solver_iteration_kernel(SphContext* ctx);             /* DFSPH.py:285-321 */
+int32_t sph_dfsph_pressure_solve_iteration_kernel(SphContext* ctx);                /* DFSPH.py:356-394 */
+int32_t sph_dfsph_divergence_solve(SphContext* ctx);               /* DFSPH.py:240-283 (loop included) */
+int32_t sph_dfsph_pressure_solve(SphContext* ctx);                 /* DFSPH.py:324-354 (loop included) */
+int32_t sph_dfsph_compute_non_pressure_forces(SphContext* ctx);    /* DFSPH.py:49-112 */
+int32_t sph_dfsph_predict_velocity(SphContext* ctx);               /* DFSPH.py:388-394 */
+int32_t sph_dfsph_advect(SphContext* ctx);                         /* DFSPH.py:100-107 */
+/* n_steps x SPHBase.step() with DFSPHSolver.substep (sph_base.py:263-271, DFSPH.py:400-408).  Phase timings:
+ * neighbour = boundary volume + density + factor, force = both solvers + non-pressure forces + predict_velocity. */
+int32_t sph_dfsph_step(SphContext* ctx, int32_t n_steps, const int32_t* dynamic_ids, int32_t n_dynamic);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Generate tests/golden/ref_*.npz by EXECUTING THE REFERENCE'S OWN SOURCE
-(/root/reference/{particle_system,sph_base,WCSPH,config_builder}.py, unmodified)
+(/root/reference/{particle_system,sph_base,WCSPH,DFSPH,config_builder}.py, unmodified)
 under the serial pure-Python `taichi` stand-in of oracle/taichi_shim/.
 
 Runs only in the build container (needs /root/reference); the .npz files it
@@ -16,6 +16,7 @@ Taichi would bake as f32 constants (domain_size) are cast to f32 up front.
 from __future__ import annotations
 
 import copy
+import io
 import json
 import os
 import sys
@@ -37,7 +38,11 @@ FIELDS = ["object_id", "x", "x_0", "v", "acceleration", "m_V", "m", "density", "
 
 
 def snapshot(ps):
-    return {f: getattr(ps, f).to_numpy().copy() for f in FIELDS}
+    out = {f: getattr(ps, f).to_numpy().copy() for f in FIELDS}
+    for f in ("dfsph_factor", "density_adv"):       # simulationMethod 4 only (particle_system.py:115-117)
+        if hasattr(ps, f):
+            out[f] = getattr(ps, f).to_numpy().copy()
+    return out
 
 
 def run_reference(scene_dict, n_steps, per_kernel_first_step=True):
@@ -60,8 +65,34 @@ def run_reference(scene_dict, n_steps, per_kernel_first_step=True):
     out = {"initial": snapshot(ps)}
     solver.initialize()
     out["initialized"] = snapshot(ps)
+    dfsph = cfg.get_cfg("simulationMethod") == 4
+    iters = []
     for s in range(n_steps):
-        if s == 0 and per_kernel_first_step:
+        if dfsph:
+            sys.stdout = buf = io.StringIO()     # "DFSPH - iteration V: k Avg density err: e" (DFSPH.py:258, 353)
+            try:
+                if s == 0 and per_kernel_first_step:
+                    # SPHBase.step() / DFSPHSolver.substep() unrolled (sph_base.py:263-271, DFSPH.py:400-408)
+                    ps.initialize_particle_system(); out["k_sort"] = snapshot(ps)
+                    solver.compute_moving_boundary_volume(); out["k_bvol"] = snapshot(ps)
+                    solver.compute_densities(); out["k_density"] = snapshot(ps)
+                    solver.compute_DFSPH_factor(); out["k_factor"] = snapshot(ps)
+                    solver.compute_density_change(); out["k_density_change"] = snapshot(ps)
+                    solver.divergence_solve(); out["k_divergence"] = snapshot(ps)
+                    solver.compute_non_pressure_forces(); out["k_nonpressure"] = snapshot(ps)
+                    solver.predict_velocity(); out["k_predict"] = snapshot(ps)
+                    solver.compute_density_adv(); out["k_density_adv"] = snapshot(ps)
+                    solver.pressure_solve(); out["k_pressure_solve"] = snapshot(ps)
+                    solver.advect(); out["k_advect"] = snapshot(ps)
+                    solver.solve_rigid_body()
+                    solver.enforce_boundary_3D(ps.material_fluid)
+                else:
+                    solver.step()
+            finally:
+                sys.stdout = sys.__stdout__
+            nums = [int(l.split(":")[1].split()[0]) for l in buf.getvalue().splitlines() if l.startswith("DFSPH")]
+            iters.append(nums)
+        elif s == 0 and per_kernel_first_step:
             # SPHBase.step() unrolled (sph_base.py:263-271) to capture every kernel's output
             ps.initialize_particle_system(); out["k_sort"] = snapshot(ps)
             solver.compute_moving_boundary_volume(); out["k_bvol"] = snapshot(ps)
@@ -75,6 +106,8 @@ def run_reference(scene_dict, n_steps, per_kernel_first_step=True):
             solver.step()
         out[f"step{s + 1}"] = snapshot(ps)
     assert ti.oob_reads == 0, f"{ti.oob_reads} out-of-range field reads: the scene hits undefined behaviour"
+    if dfsph:
+        out["solver"] = {"iterations": np.array(iters, dtype=np.int32)}   # [step][divergence, pressure]
     return out
 
 
@@ -93,7 +126,21 @@ def main():
         "ref_fluid_rigid": (scenes.fluid_with_rigid_blocks(fluid_counts=(8, 8, 6), static_counts=(12, 2, 10),
                                                            dyn_counts=(4, 4, 4)), 8),
     }
+    # DFSPH (simulationMethod 4, DFSPH.py): fluid hitting a wall corner; fluid on a static slab with a dynamic block
+    d1 = scenes.fluid_only(counts=(8, 9, 6), start=(0.05, 0.05, 0.05), velocity=(-4.0, -6.0, -3.0),
+                           domain_end=(0.6, 0.6, 0.5))      # both solvers iterate (up to 3 / 2 extra iterations)
+    d2 = scenes.fluid_with_rigid_blocks(fluid_counts=(8, 8, 6), static_counts=(12, 2, 10), dyn_counts=(4, 4, 4))
+    d2["FluidBlocks"][0]["velocity"] = [0.0, 0.0, 0.0]
+    d2["RigidBlocks"][1]["velocity"] = [0.0, -8.0, 0.0]     # the cube hits the fluid: coupling reaction of DFSPH.py:394
+    for d in (d1, d2):
+        d["Configuration"]["simulationMethod"] = 4
+        d["Configuration"]["timeStepSize"] = 0.002
+    jobs["ref_dfsph_wall"] = (d1, 8)
+    jobs["ref_dfsph_rigid"] = (d2, 8)
+    only = sys.argv[1:]
     for name, (sd, steps) in jobs.items():
+        if only and name not in only:
+            continue
         t0 = time.time()
         res = run_reference(copy.deepcopy(sd), steps)
         path = os.path.join(ROOT, "tests", "golden", name + ".npz")

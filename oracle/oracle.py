@@ -51,6 +51,13 @@ class _State(C.Structure):
         ("grid_particles_num", _pi), ("grid_particles_num_temp", _pi),
         ("rigid_rest_cm", _pf),
         ("pid", _pi), ("pid_buffer", _pi),
+        # DFSPH (simulationMethod 4)
+        ("simulation_method", C.c_int32), ("fluid_particle_num", C.c_int32), ("enable_divergence_solver", C.c_int32),
+        ("m_max_iterations_v", C.c_int32), ("m_max_iterations", C.c_int32), ("m_eps", C.c_float),
+        ("max_error_V", C.c_double), ("max_error", C.c_double),
+        ("last_iterations_v", C.c_int32), ("last_iterations", C.c_int32),
+        ("last_avg_err_v", C.c_double), ("last_avg_err", C.c_double),
+        ("dfsph_factor", _pf), ("density_adv", _pf), ("dfsph_factor_buffer", _pf), ("density_adv_buffer", _pf),
     ]
 
 
@@ -71,10 +78,22 @@ def lib():
         for name in ("update_grid_id", "prefix_sum", "counting_sort", "initialize_particle_system",
                      "compute_static_boundary_volume", "compute_moving_boundary_volume",
                      "compute_densities", "compute_non_pressure_forces", "compute_pressure_forces",
-                     "advect", "substep"):
+                     "advect", "substep", "dfsph_compute_densities", "dfsph_compute_non_pressure_forces",
+                     "dfsph_compute_factor", "dfsph_compute_density_change", "dfsph_compute_density_adv",
+                     "dfsph_divergence_solver_iteration_kernel", "dfsph_pressure_solve_iteration_kernel",
+                     "dfsph_divergence_solve", "dfsph_pressure_solve", "dfsph_predict_velocity", "dfsph_advect",
+                     "dfsph_substep"):
             f = getattr(L, "oracle_" + name)
             f.argtypes = [ps]
             f.restype = None
+        L.oracle_dfsph_compute_density_error.argtypes = [ps, C.c_float]
+        L.oracle_dfsph_compute_density_error.restype = C.c_float
+        L.oracle_dfsph_multiply_time_step.argtypes = [ps, C.c_float]
+        L.oracle_dfsph_multiply_time_step.restype = None
+        for name in ("dfsph_divergence_solver_iteration", "dfsph_pressure_solve_iteration"):
+            f = getattr(L, "oracle_" + name)
+            f.argtypes = [ps]
+            f.restype = C.c_double
         L.oracle_enforce_boundary_3D.argtypes = [ps, C.c_int32]
         L.oracle_compute_rigid_rest_cm.argtypes = [ps, C.c_int32]
         L.oracle_solve_constraints.argtypes = [ps, C.c_int32, _pf]
@@ -106,7 +125,8 @@ class Oracle:
     """One simulation state + the reference's per-kernel methods.
 
     params: dict with particle_radius, domain_size[3], density_0, stiffness,
-    exponent, dt, g[3]  (values as the scene JSON gives them).
+    exponent, dt, g[3]  (values as the scene JSON gives them); simulation_method 4 selects the DFSPH
+    step (DFSPH.py) with its solver knobs at the reference's defaults (DFSPH.py:12-20).
     arrays: dict of the reference's per-particle arrays (any missing one is
     zero-initialised).  rigid_body_ids: ids in ps.object_id_rigid_body;
     dynamic_ids: those with isDynamic.
@@ -173,6 +193,20 @@ class Oracle:
             arr = np.zeros(size, dtype=np.int32)
             self.a[n] = arr
             setattr(s, n, arr.ctypes.data_as(_pi))
+        # DFSPH state (particle_system.py:115-117, 134-135) and solver knobs (DFSPH.py:12-20)
+        s.simulation_method = int(params.get("simulation_method", 0))
+        mat = self.a["material"]
+        s.fluid_particle_num = int(params.get("fluid_particle_num", int((mat == 1).sum())))
+        s.enable_divergence_solver = int(params.get("enable_divergence_solver", True))
+        s.m_max_iterations_v = int(params.get("m_max_iterations_v", 100))
+        s.m_max_iterations = int(params.get("m_max_iterations", 100))
+        s.m_eps = float(params.get("m_eps", 1e-5))
+        s.max_error_V = float(params.get("max_error_V", 0.1))
+        s.max_error = float(params.get("max_error", 0.05))
+        for n in ("dfsph_factor", "density_adv", "dfsph_factor_buffer", "density_adv_buffer"):
+            arr = np.zeros(N, dtype=np.float32)
+            self.a[n] = arr
+            setattr(s, n, arr.ctypes.data_as(_pf))
         self.a["rigid_rest_cm"] = np.zeros((max(int(n_objects), 1), 3), dtype=np.float32)
         s.rigid_rest_cm = self.a["rigid_rest_cm"].ctypes.data_as(_pf)
         self.s = s
@@ -214,6 +248,22 @@ class Oracle:
     def compute_pressure_forces(self): self.L.oracle_compute_pressure_forces(self._p())
     def advect(self): self.L.oracle_advect(self._p())
     def substep(self): self.L.oracle_substep(self._p())
+    # DFSPH.py method surface
+    def compute_DFSPH_factor(self): self.L.oracle_dfsph_compute_factor(self._p())
+    def compute_density_change(self): self.L.oracle_dfsph_compute_density_change(self._p())
+    def compute_density_adv(self): self.L.oracle_dfsph_compute_density_adv(self._p())
+    def compute_density_error(self, offset): return float(self.L.oracle_dfsph_compute_density_error(self._p(), float(offset)))
+    def multiply_time_step(self, time_step): self.L.oracle_dfsph_multiply_time_step(self._p(), float(time_step))
+    def divergence_solver_iteration_kernel(self): self.L.oracle_dfsph_divergence_solver_iteration_kernel(self._p())
+    def pressure_solve_iteration_kernel(self): self.L.oracle_dfsph_pressure_solve_iteration_kernel(self._p())
+    def divergence_solver_iteration(self): return float(self.L.oracle_dfsph_divergence_solver_iteration(self._p()))
+    def pressure_solve_iteration(self): return float(self.L.oracle_dfsph_pressure_solve_iteration(self._p()))
+    def divergence_solve(self): self.L.oracle_dfsph_divergence_solve(self._p()); return self.s.last_iterations_v
+    def pressure_solve(self): self.L.oracle_dfsph_pressure_solve(self._p()); return self.s.last_iterations
+    def predict_velocity(self): self.L.oracle_dfsph_predict_velocity(self._p())
+    def dfsph_advect(self): self.L.oracle_dfsph_advect(self._p())
+    def dfsph_substep(self): self.L.oracle_dfsph_substep(self._p())
+
     def enforce_boundary_3D(self, particle_type): self.L.oracle_enforce_boundary_3D(self._p(), int(particle_type))
     def compute_rigid_rest_cm(self, object_id): self.L.oracle_compute_rigid_rest_cm(self._p(), int(object_id))
 

@@ -1,5 +1,5 @@
 /*
- * sph_oracle.c -- CPU restatement of erizmr/SPH_Taichi's WCSPH step.
+ * sph_oracle.c -- CPU restatement of erizmr/SPH_Taichi's WCSPH step (and, further down, of its DFSPH step).
  *
  * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (sph_taichi_amd/) may
  * import, link or call this file.  It is used by tests/, by
@@ -10,7 +10,7 @@
  * Taichi cannot be installed in this image.  The restatement is pinned in two
  * ways (see oracle/README.md and DESIGN.md):
  *   1. tests/golden/ref_*.npz are produced by EXECUTING THE REFERENCE'S OWN
- *      SOURCE FILES (particle_system.py, sph_base.py, WCSPH.py, unmodified,
+ *      SOURCE FILES (particle_system.py, sph_base.py, WCSPH.py, DFSPH.py, unmodified,
  *      from /root/reference) under a serial pure-Python stand-in for the
  *      `taichi` module (oracle/taichi_shim/, generator oracle/gen_golden.py).
  *      That pins every formula and the traversal order; it cannot pin Taichi's
@@ -79,6 +79,21 @@ typedef struct OracleState {
     /* extra (not in the reference): persistent particle id carried through the
      * sort so tests can compare per particle. */
     int32_t *pid; int32_t *pid_buffer;
+    /* ---- DFSPH (simulationMethod 4) ---- */
+    int32_t simulation_method;        /* 0 WCSPH, 4 DFSPH            particle_system.py:27, 214-221 */
+    int32_t fluid_particle_num;       /* particle_system.py:57-62 */
+    int32_t enable_divergence_solver; /* DFSPH.py:12 */
+    int32_t m_max_iterations_v;       /* DFSPH.py:14 */
+    int32_t m_max_iterations;         /* DFSPH.py:15 */
+    float m_eps;                      /* DFSPH.py:17 */
+    double max_error_V;               /* DFSPH.py:19 (Python-scope floats stay f64) */
+    double max_error;                 /* DFSPH.py:20 */
+    int32_t last_iterations_v;        /* what the reference prints at DFSPH.py:258 / :353 */
+    int32_t last_iterations;
+    double last_avg_err_v;
+    double last_avg_err;
+    float *dfsph_factor; float *density_adv;               /* particle_system.py:116-117 */
+    float *dfsph_factor_buffer; float *density_adv_buffer; /* particle_system.py:134-135 */
 } OracleState;
 
 #define MATERIAL_SOLID 0 /* particle_system.py:30 */
@@ -171,6 +186,10 @@ void oracle_counting_sort(OracleState *s) {
         memcpy(&s->color_buffer[3 * n], &s->color[3 * I], 12);
         s->is_dynamic_buffer[n] = s->is_dynamic[I];
         s->pid_buffer[n] = s->pid[I];
+        if (s->simulation_method == 4) { /* particle_system.py:348-350 */
+            s->dfsph_factor_buffer[n] = s->dfsph_factor[I];
+            s->density_adv_buffer[n] = s->density_adv[I];
+        }
     }
 #pragma omp parallel for schedule(static)
     for (int32_t I = 0; I < N; ++I) {
@@ -188,6 +207,10 @@ void oracle_counting_sort(OracleState *s) {
         memcpy(&s->color[3 * I], &s->color_buffer[3 * I], 12);
         s->is_dynamic[I] = s->is_dynamic_buffer[I];
         s->pid[I] = s->pid_buffer[I];
+        if (s->simulation_method == 4) { /* particle_system.py:367-369 */
+            s->dfsph_factor[I] = s->dfsph_factor_buffer[I];
+            s->density_adv[I] = s->density_adv_buffer[I];
+        }
     }
 }
 
@@ -588,6 +611,237 @@ void oracle_substep(OracleState *s) {
     oracle_advect(s);
 }
 
+
+/* ======================================================================================
+ * DFSPH (DFSPH.py).  Same neighbour traversal, same f32 conventions.  Host-side loop
+ * arithmetic (eta, averages, 1/dt) is Python f64 in the reference and double here.
+ * ==================================================================================== */
+
+/* DFSPH.py:22-47  compute_densities: formula identical to WCSPH.py:19-43 */
+void oracle_dfsph_compute_densities(OracleState *s) { oracle_compute_densities(s); }
+
+/* DFSPH.py:49-97  compute_non_pressure_forces: surface tension + viscosity as WCSPH.py:88-140; the solid
+ * branch carries boundary_viscosity = 0.0, so it (and its scatter to dynamic bodies) adds exactly 0. */
+void oracle_dfsph_compute_non_pressure_forces(OracleState *s) { oracle_compute_non_pressure_forces(s); }
+
+/* grad_p_j = -m_V[p_j] * cubic_kernel_derivative(x_i - x_j)   (DFSPH.py:144, 151, 297, 303, 376, 383) */
+static inline void grad_p(const OracleState *s, int32_t p_j, const float r[3], float g[3]) {
+    float gw[3];
+    cubic_kernel_derivative(s, r, gw);
+    const float c = -s->m_V[p_j];
+    g[0] = c * gw[0]; g[1] = c * gw[1]; g[2] = c * gw[2];
+}
+static inline float dot3(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+/* DFSPH.py:116-154  compute_DFSPH_factor (+ task) */
+void oracle_dfsph_compute_factor(OracleState *s) {
+    set_threads(s);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int32_t p_i = 0; p_i < s->N; ++p_i) {
+        if (s->material[p_i] != MATERIAL_FLUID) continue;
+        float ret[4] = {0.0f, 0.0f, 0.0f, 0.0f}; /* grad_p_i, sum_grad_p_k */
+        NEIGHBOR_LOOP_BEGIN(s, p_i, p_j)
+        float g[3];
+        grad_p(s, p_j, rr_, g);
+        if (s->material[p_j] == MATERIAL_FLUID) ret[3] += dot3(g, g);
+        ret[0] -= g[0]; ret[1] -= g[1]; ret[2] -= g[2]; /* both materials */
+        NEIGHBOR_LOOP_END
+        float sum_grad_p_k = ret[3];
+        sum_grad_p_k += dot3(ret, ret);
+        s->dfsph_factor[p_i] = sum_grad_p_k > 1e-6f ? -1.0f / sum_grad_p_k : 0.0f;
+    }
+}
+
+/* sum_j m_V_j (v_i - v_j) . gradW(x_i - x_j) over both materials, and the neighbour count
+ * (DFSPH.py:183-197 compute_density_change_task / :212-221 compute_density_adv_task) */
+static inline float velocity_divergence(const OracleState *s, int32_t p_i, int32_t *count) {
+    float acc = 0.0f;
+    int32_t n = 0;
+    const float *vi = &s->v[3 * p_i];
+    NEIGHBOR_LOOP_BEGIN(s, p_i, p_j)
+    float gw[3];
+    cubic_kernel_derivative(s, rr_, gw);
+    const float *vj = &s->v[3 * p_j];
+    const float dv[3] = {vi[0] - vj[0], vi[1] - vj[1], vi[2] - vj[2]};
+    acc += s->m_V[p_j] * dot3(dv, gw);
+    n += 1;
+    NEIGHBOR_LOOP_END
+    if (count) *count = n;
+    return acc;
+}
+
+/* DFSPH.py:157-180  compute_density_change */
+void oracle_dfsph_compute_density_change(OracleState *s) {
+    set_threads(s);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int32_t p_i = 0; p_i < s->N; ++p_i) {
+        if (s->material[p_i] != MATERIAL_FLUID) continue;
+        int32_t num_neighbors = 0;
+        float density_adv = fmaxf(velocity_divergence(s, p_i, &num_neighbors), 0.0f); /* only positive divergence */
+        if (num_neighbors < 20) density_adv = 0.0f;                                    /* dim == 3  DFSPH.py:172-174 */
+        s->density_adv[p_i] = density_adv;
+    }
+}
+
+/* DFSPH.py:200-209  compute_density_adv */
+void oracle_dfsph_compute_density_adv(OracleState *s) {
+    set_threads(s);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int32_t p_i = 0; p_i < s->N; ++p_i) {
+        if (s->material[p_i] != MATERIAL_FLUID) continue;
+        const float delta = velocity_divergence(s, p_i, NULL);
+        const float density_adv = s->density[p_i] / s->density_0 + s->dt * delta;
+        s->density_adv[p_i] = fmaxf(density_adv, 1.0f);
+    }
+}
+
+/* DFSPH.py:224-230  compute_density_error: f32 sum in index order (a serial run of the reference's reduction) */
+float oracle_dfsph_compute_density_error(const OracleState *s, float offset) {
+    float density_error = 0.0f;
+    for (int32_t I = 0; I < s->N; ++I)
+        if (s->material[I] == MATERIAL_FLUID) density_error += s->density_0 * s->density_adv[I] - offset;
+    return density_error;
+}
+
+/* DFSPH.py:233-237  multiply_time_step (only ever applied to dfsph_factor) */
+void oracle_dfsph_multiply_time_step(OracleState *s, float time_step) {
+    for (int32_t I = 0; I < s->N; ++I)
+        if (s->material[I] == MATERIAL_FLUID) s->dfsph_factor[I] *= time_step;
+}
+
+/* DFSPH.py:285-321 divergence_solver_iteration_kernel (+ task)  [pressure = 0]
+ * DFSPH.py:356-394 pressure_solve_iteration_kernel (+ task)     [pressure = 1]
+ * The two differ in b (density_adv vs density_adv - 1), in accumulating dv vs updating v[p_i] in place, and in
+ * how the reaction on a dynamic body divides by dt. */
+static void solver_iteration_kernel(OracleState *s, int pressure) {
+    set_threads(s);
+    const float dt = s->dt;
+    const float off = pressure ? 1.0f : 0.0f;
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int32_t p_i = 0; p_i < s->N; ++p_i) {
+        if (s->material[p_i] != MATERIAL_FLUID) continue;
+        const float b_i = s->density_adv[p_i] - off;
+        const float k_i = b_i * s->dfsph_factor[p_i];
+        float dv[3] = {0.0f, 0.0f, 0.0f};
+        float *v = &s->v[3 * p_i];
+        NEIGHBOR_LOOP_BEGIN(s, p_i, p_j)
+        if (s->material[p_j] == MATERIAL_FLUID) {
+            const float b_j = s->density_adv[p_j] - off;
+            const float k_j = b_j * s->dfsph_factor[p_j];
+            const float k_sum = k_i + s->density_0 / s->density_0 * k_j;
+            if (fabsf(k_sum) > s->m_eps) {
+                float g[3];
+                grad_p(s, p_j, rr_, g);
+                const float c = dt * k_sum;
+                if (pressure) { v[0] -= c * g[0]; v[1] -= c * g[1]; v[2] -= c * g[2]; }
+                else { dv[0] -= c * g[0]; dv[1] -= c * g[1]; dv[2] -= c * g[2]; }
+            }
+        } else if (s->material[p_j] == MATERIAL_SOLID) {
+            if (fabsf(k_i) > s->m_eps) {
+                float g[3];
+                grad_p(s, p_j, rr_, g);
+                const float c = -dt * 1.0f * k_i;
+                const float vel_change[3] = {c * g[0], c * g[1], c * g[2]};
+                if (pressure) { v[0] += vel_change[0]; v[1] += vel_change[1]; v[2] += vel_change[2]; }
+                else { dv[0] += vel_change[0]; dv[1] += vel_change[1]; dv[2] += vel_change[2]; }
+                if (is_dynamic_rigid_body(s, p_j)) {
+                    float back[3];
+                    for (int d = 0; d < 3; ++d)
+                        back[d] = pressure ? -vel_change[d] * 1.0f / dt * s->density[p_i] / s->density[p_j]           /* :394 */
+                                           : -vel_change[d] * (1.0f / dt) * s->density[p_i] / s->density[p_j];        /* :321 */
+                    atomic_add3(&s->acceleration[3 * p_j], back);
+                }
+            }
+        }
+        NEIGHBOR_LOOP_END
+        if (!pressure) { v[0] += dv[0]; v[1] += dv[1]; v[2] += dv[2]; }
+    }
+}
+void oracle_dfsph_divergence_solver_iteration_kernel(OracleState *s) { solver_iteration_kernel(s, 0); }
+void oracle_dfsph_pressure_solve_iteration_kernel(OracleState *s) { solver_iteration_kernel(s, 1); }
+
+/* DFSPH.py:278-283 */
+double oracle_dfsph_divergence_solver_iteration(OracleState *s) {
+    oracle_dfsph_divergence_solver_iteration_kernel(s);
+    oracle_dfsph_compute_density_change(s);
+    const float density_err = oracle_dfsph_compute_density_error(s, 0.0f);
+    return (double)density_err / s->fluid_particle_num;
+}
+
+/* DFSPH.py:240-275 */
+void oracle_dfsph_divergence_solve(OracleState *s) {
+    oracle_dfsph_compute_density_change(s);
+    const double dt = (double)s->dt;
+    const double inv_dt = 1 / dt;
+    oracle_dfsph_multiply_time_step(s, (float)inv_dt);
+    int32_t m_iterations_v = 0;
+    double avg_density_err = 0.0;
+    while (m_iterations_v < 1 || m_iterations_v < s->m_max_iterations_v) {
+        avg_density_err = oracle_dfsph_divergence_solver_iteration(s);
+        const double eta = 1.0 / dt * s->max_error_V * 0.01 * (double)s->density_0;
+        if (avg_density_err <= eta) break;
+        m_iterations_v += 1;
+    }
+    s->last_iterations_v = m_iterations_v;
+    s->last_avg_err_v = avg_density_err;
+    oracle_dfsph_multiply_time_step(s, (float)dt);
+}
+
+/* DFSPH.py:350-354 */
+double oracle_dfsph_pressure_solve_iteration(OracleState *s) {
+    oracle_dfsph_pressure_solve_iteration_kernel(s);
+    oracle_dfsph_compute_density_adv(s);
+    const float density_err = oracle_dfsph_compute_density_error(s, s->density_0);
+    return (double)density_err / s->fluid_particle_num;
+}
+
+/* DFSPH.py:324-348 */
+void oracle_dfsph_pressure_solve(OracleState *s) {
+    const double dt = (double)s->dt;
+    const double inv_dt2 = 1 / (dt * dt);
+    oracle_dfsph_compute_density_adv(s);
+    oracle_dfsph_multiply_time_step(s, (float)inv_dt2);
+    int32_t m_iterations = 0;
+    double avg_density_err = 0.0;
+    while (m_iterations < 1 || m_iterations < s->m_max_iterations) {
+        avg_density_err = oracle_dfsph_pressure_solve_iteration(s);
+        const double eta = s->max_error * 0.01 * (double)s->density_0;
+        if (avg_density_err <= eta) break;
+        m_iterations += 1;
+    }
+    s->last_iterations = m_iterations;
+    s->last_avg_err = avg_density_err;
+}
+
+/* DFSPH.py:388-394  predict_velocity */
+void oracle_dfsph_predict_velocity(OracleState *s) {
+    for (int32_t p = 0; p < s->N; ++p)
+        if (s->is_dynamic[p] && s->material[p] == MATERIAL_FLUID)
+            for (int d = 0; d < 3; ++d) s->v[3 * p + d] += s->dt * s->acceleration[3 * p + d];
+}
+
+/* DFSPH.py:100-107  advect: only dynamic rigid particles integrate their acceleration here */
+void oracle_dfsph_advect(OracleState *s) {
+    for (int32_t p = 0; p < s->N; ++p) {
+        if (!s->is_dynamic[p]) continue;
+        for (int d = 0; d < 3; ++d) {
+            if (is_dynamic_rigid_body(s, p)) s->v[3 * p + d] += s->dt * s->acceleration[3 * p + d];
+            s->x[3 * p + d] += s->dt * s->v[3 * p + d];
+        }
+    }
+}
+
+/* DFSPH.py:400-408  substep */
+void oracle_dfsph_substep(OracleState *s) {
+    oracle_dfsph_compute_densities(s);
+    oracle_dfsph_compute_factor(s);
+    if (s->enable_divergence_solver) oracle_dfsph_divergence_solve(s);
+    oracle_dfsph_compute_non_pressure_forces(s);
+    oracle_dfsph_predict_velocity(s);
+    oracle_dfsph_pressure_solve(s);
+    oracle_dfsph_advect(s);
+}
+
 /* sph_base.py:247-260  solve_rigid_body;  dyn_ids = ids of dynamic RigidBodies */
 void oracle_solve_rigid_body(OracleState *s, const int32_t *dyn_ids, int32_t n_dyn) {
     for (int32_t k = 0; k < n_dyn; ++k) {
@@ -611,12 +865,25 @@ void oracle_step(OracleState *s, const int32_t *dyn_ids, int32_t n_dyn, int32_t 
         oracle_initialize_particle_system(s);
         double t1 = now_ms();
         oracle_compute_moving_boundary_volume(s);
-        oracle_compute_densities(s);
-        double t2 = now_ms();
-        oracle_compute_non_pressure_forces(s);
-        oracle_compute_pressure_forces(s);
-        double t3 = now_ms();
-        oracle_advect(s);
+        double t2, t3;
+        if (s->simulation_method == 4) { /* DFSPHSolver.substep: density + factor | solvers + forces | advect */
+            oracle_dfsph_compute_densities(s);
+            oracle_dfsph_compute_factor(s);
+            t2 = now_ms();
+            if (s->enable_divergence_solver) oracle_dfsph_divergence_solve(s);
+            oracle_dfsph_compute_non_pressure_forces(s);
+            oracle_dfsph_predict_velocity(s);
+            oracle_dfsph_pressure_solve(s);
+            t3 = now_ms();
+            oracle_dfsph_advect(s);
+        } else {
+            oracle_compute_densities(s);
+            t2 = now_ms();
+            oracle_compute_non_pressure_forces(s);
+            oracle_compute_pressure_forces(s);
+            t3 = now_ms();
+            oracle_advect(s);
+        }
         oracle_solve_rigid_body(s, dyn_ids, n_dyn);
         oracle_enforce_boundary_3D(s, MATERIAL_FLUID);
         double t4 = now_ms();

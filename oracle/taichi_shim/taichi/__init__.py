@@ -3,7 +3,7 @@
 Purpose: Taichi cannot be installed in this image, so the reference
 (/root/reference/*.py, Python that only runs under Taichi) cannot be executed as
 is.  This package implements just enough of the Taichi API for the reference's
-OWN, UNMODIFIED source files (particle_system.py, sph_base.py, WCSPH.py,
+OWN, UNMODIFIED source files (particle_system.py, sph_base.py, WCSPH.py, DFSPH.py,
 config_builder.py) to be imported and run on the CPU, one loop iteration at a
 time, with f32 / i32 arithmetic done by NumPy scalars.  oracle/gen_golden.py uses
 it to produce the golden vectors under tests/golden/ that pin oracle/sph_oracle.c.
@@ -114,6 +114,9 @@ class Vec(np.ndarray):
 
     def norm(self):
         return np.sqrt(np.sum(self * self, dtype=self.dtype))
+
+    def norm_sqr(self):
+        return np.sum(np.asarray(self) * np.asarray(self), dtype=self.dtype)
 
     def dot(self, other):
         return np.sum(np.asarray(self) * np.asarray(other), dtype=self.dtype)
@@ -255,6 +258,17 @@ def sqrt(x):
     return np.sqrt(x)
 
 
+def abs(x):  # noqa: A001
+    return np.abs(_unbox(x))
+
+
+class Struct:
+    """ti.Struct(**members): a mutable record (members keep NumPy f32 / Python-weak scalar semantics)."""
+
+    def __init__(self, **members):
+        self.__dict__.update(members)
+
+
 def polar_decompose(A):
     a = np.asarray(A, dtype=np.float64)
     U, s, Vt = np.linalg.svd(a)
@@ -308,10 +322,48 @@ def loop_config(**k):
 # kernel / func: AST rewrite for pass-by-reference templates and atomics
 # ---------------------------------------------------------------------------
 class Box:
+    """Cell that carries a ti.template() argument by reference.  `x += ...` on the parameter name rebinds the
+    cell's value (see _aug); reads of a boxed scalar, `ret[k] += ...` on a boxed Vector and `ret.member += ...` on
+    a boxed Struct go through to the value."""
     __slots__ = ("v",)
 
     def __init__(self, v):
-        self.v = v
+        object.__setattr__(self, "v", v)
+
+    def __getattr__(self, name):
+        return getattr(object.__getattribute__(self, "v"), name)
+
+    def __setattr__(self, name, value):
+        if name == "v":
+            object.__setattr__(self, "v", value)
+        else:
+            setattr(self.v, name, value)
+
+    def __getitem__(self, k):
+        return self.v[k]
+
+    def __setitem__(self, k, value):
+        self.v[k] = value
+
+    def __add__(self, o): return self.v + _unbox(o)
+    def __radd__(self, o): return _unbox(o) + self.v
+    def __sub__(self, o): return self.v - _unbox(o)
+    def __rsub__(self, o): return _unbox(o) - self.v
+    def __mul__(self, o): return self.v * _unbox(o)
+    def __rmul__(self, o): return _unbox(o) * self.v
+    def __truediv__(self, o): return self.v / _unbox(o)
+    def __rtruediv__(self, o): return _unbox(o) / self.v
+    def __neg__(self): return -self.v
+    def __abs__(self): return np.abs(self.v)
+    def __lt__(self, o): return self.v < _unbox(o)
+    def __le__(self, o): return self.v <= _unbox(o)
+    def __gt__(self, o): return self.v > _unbox(o)
+    def __ge__(self, o): return self.v >= _unbox(o)
+    def __float__(self): return float(self.v)
+
+
+def _unbox(x):
+    return x.v if isinstance(x, Box) else x
 
 
 _OPS = {ast.Add: lambda a, b: a + b, ast.Sub: lambda a, b: a - b, ast.Mult: lambda a, b: a * b,
@@ -452,7 +504,7 @@ class _TiCallable:
         ast.fix_missing_locations(tree)
         g = dict(self.fn.__globals__)
         g.update(__ti_aug=_aug, __ti_atomic=_atomic, __ti_box_args=_box_args, __ti_after=_after,
-                 all=_ti_all, abs=np.abs)
+                 all=_ti_all, abs=abs)
         code = compile(tree, filename=f"<ti-shim:{self.fn.__qualname__}>", mode="exec")
         exec(code, g)
         self.compiled = g[fdef.name]

@@ -10,6 +10,7 @@ from .config_builder import SimConfig
 from .particle_system import ParticleSystem
 from .sph_base import SPHBase
 from .WCSPH import WCSPHSolver
+from .DFSPH import DFSPHSolver
 
-__all__ = ["SimConfig", "ParticleSystem", "SPHBase", "WCSPHSolver"]
+__all__ = ["SimConfig", "ParticleSystem", "SPHBase", "WCSPHSolver", "DFSPHSolver"]
 __version__ = "0.1.0"

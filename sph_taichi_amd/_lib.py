@@ -33,9 +33,21 @@ class SphTimings(C.Structure):
                 ("steps", C.c_int64)]
 
 
+class SphDfsphParams(C.Structure):
+    _fields_ = [("enable_divergence_solver", C.c_int32), ("m_max_iterations_v", C.c_int32),
+                ("m_max_iterations", C.c_int32), ("fluid_particle_num", C.c_int32), ("m_eps", C.c_float),
+                ("reserved_", C.c_float), ("max_error_V", C.c_double), ("max_error", C.c_double)]
+
+
+class SphDfsphStats(C.Structure):
+    _fields_ = [("iterations_v", C.c_int32), ("iterations", C.c_int32), ("avg_density_err_v", C.c_double),
+                ("avg_density_err", C.c_double), ("total_iterations_v", C.c_int64), ("total_iterations", C.c_int64),
+                ("steps", C.c_int64)]
+
+
 # enum SphField
 F_OBJECT_ID, F_X, F_X_0, F_V, F_ACCELERATION, F_M_V, F_M, F_DENSITY, F_PRESSURE, F_MATERIAL, F_COLOR, \
-    F_IS_DYNAMIC, F_GRID_IDS, F_GRID_PARTICLES_NUM, F_PID, F_RIGID_REST_CM = range(16)
+    F_IS_DYNAMIC, F_GRID_IDS, F_GRID_PARTICLES_NUM, F_PID, F_RIGID_REST_CM, F_DFSPH_FACTOR, F_DENSITY_ADV = range(18)
 # enum SphOption
 OPT_GATHER_IMPL, OPT_TIMING, OPT_FUSED_STEP, OPT_BRICK_SHAPE, OPT_NO_DYNAMIC_SOLIDS, OPT_DEBUG_ABLATE, \
     OPT_SLAB_DROP_OUTSIDE = range(7)
@@ -95,6 +107,22 @@ SYMBOLS = [
     ("sph_rigid_partial_sums", C.c_int32, [_ctx, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     ("sph_rigid_apply_sums", C.c_int32, [_ctx, C.c_int32, C.c_void_p, C.c_int32]),
     ("sph_upload_rest_positions", C.c_int32, [_ctx, C.c_void_p, C.c_void_p, C.c_int32]),
+    ("sph_dfsph_set_params", C.c_int32, [_ctx, C.POINTER(SphDfsphParams)]),
+    ("sph_dfsph_get_stats", C.c_int32, [_ctx, C.POINTER(SphDfsphStats)]),
+    ("sph_dfsph_compute_densities", C.c_int32, [_ctx]),
+    ("sph_dfsph_compute_DFSPH_factor", C.c_int32, [_ctx]),
+    ("sph_dfsph_compute_density_change", C.c_int32, [_ctx]),
+    ("sph_dfsph_compute_density_adv", C.c_int32, [_ctx]),
+    ("sph_dfsph_compute_density_error", C.c_int32, [_ctx, C.c_float, C.POINTER(C.c_float)]),
+    ("sph_dfsph_multiply_time_step", C.c_int32, [_ctx, C.c_float]),
+    ("sph_dfsph_divergence_solver_iteration_kernel", C.c_int32, [_ctx]),
+    ("sph_dfsph_pressure_solve_iteration_kernel", C.c_int32, [_ctx]),
+    ("sph_dfsph_divergence_solve", C.c_int32, [_ctx]),
+    ("sph_dfsph_pressure_solve", C.c_int32, [_ctx]),
+    ("sph_dfsph_compute_non_pressure_forces", C.c_int32, [_ctx]),
+    ("sph_dfsph_predict_velocity", C.c_int32, [_ctx]),
+    ("sph_dfsph_advect", C.c_int32, [_ctx]),
+    ("sph_dfsph_step", C.c_int32, [_ctx, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
 ]
 
 _LIB = None

@@ -43,6 +43,7 @@ DevView sph_view(const SphContext* c) {
     d.xm = c->xm[c->cur] + o; d.vf = c->vf[c->cur] + o; d.aux = c->aux[c->cur] + o; d.key = c->key[c->cur] + o;
     d.eos = c->eos; d.acc = c->acc + o; d.cell_end = c->cell_end;
     d.x0_cold = c->x0_cold; d.rigid_rest_cm = c->rigid_rest_cm;
+    d.m_eps = c->df.m_eps;
     return d;
 }
 
@@ -140,6 +141,7 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     c->rigid_part_blocks = (c->cap + 255) / 256 + 1;
     rc = rc ? rc : alloc_dev(c, (void**)&c->rigid_part, (size_t)c->rigid_part_blocks * 16 * sizeof(double));
     rc = rc ? rc : alloc_dev(c, (void**)&c->rigid_R, 16 * sizeof(float));
+    rc = rc ? rc : alloc_dev(c, (void**)&c->df_err, sizeof(double));
     c->stage_bytes = cap * 16 > (size_t)c->G * 4 ? cap * 16 : (size_t)c->G * 4;
     rc = rc ? rc : alloc_dev(c, &c->stage, c->stage_bytes);
     if (!rc && hipHostMalloc((void**)&c->h_pinned, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess) rc = SPH_E_NOMEM;
@@ -156,6 +158,10 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
         return rc;
     }
     c->n_dyn_host = -1;  // unknown until material / is_dynamic are uploaded
+    c->lists_valid = false;
+    memset(&c->df_stats, 0, sizeof(c->df_stats));
+    c->df.enable_divergence_solver = 1; c->df.m_max_iterations_v = 100; c->df.m_max_iterations = 100;  // DFSPH.py:12-20
+    c->df.fluid_particle_num = 0; c->df.m_eps = 1e-5f; c->df.reserved_ = 0.0f; c->df.max_error_V = 0.1; c->df.max_error = 0.05;
     *out = c;
     return 0;
 }
@@ -166,7 +172,7 @@ int32_t sph_destroy(SphContext* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->xm[0], c->xm[1], c->vf[0], c->vf[1], c->aux[0], c->aux[1], c->key[0], c->key[1], c->eos, c->acc,
                     c->acc_tmp, c->cell_end, c->rank_off, c->idx_unstable, c->scan_sums, c->x0_cold, c->color_cold,
-                    c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->rigid_part, c->rigid_R, c->stage, c->glist, c->gcnt, c->brick_list, c->brick_count};
+                    c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->rigid_part, c->rigid_R, c->df_err, c->stage, c->glist, c->gcnt, c->brick_list, c->brick_count};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < SPH_MAX_TIMED_STEPS; ++s)
         for (int k = 0; k < 5; ++k) if (c->ev[s][k]) (void)hipEventDestroy(c->ev[s][k]);
@@ -226,6 +232,7 @@ int32_t sph_set_particle_count(SphContext* c, int32_t n) {
     if (!c || n < 0 || n > c->cap) return sph_fail(c, SPH_E_INVALID, "particle count out of range");
     c->N = n;
     c->n_dyn_host = -1;
+    c->lists_valid = false;
     c->have_keys = c->have_prefix = false;
     return 0;
 }
@@ -569,6 +576,7 @@ int32_t sph_select_range(SphContext* c, int32_t first, int32_t count) {
     if (first < 0 || count < 0 || first + count > c->in_off + c->N) return sph_fail(c, SPH_E_INVALID, "sph_select_range: out of range");
     c->in_off += first;
     c->N = count;
+    c->lists_valid = false;
     c->have_keys = c->have_prefix = c->sorted = false;
     c->n_dyn_host = -1;
     return 0;
@@ -604,6 +612,7 @@ int32_t sph_append_records(SphContext* c, const void* src, int32_t count) {
     SPH_HIP(c, hipMemcpyAsync(c->vf[c->cur] + o, s + b, b, hipMemcpyDeviceToDevice, c->stream));
     SPH_HIP(c, hipMemcpyAsync(c->aux[c->cur] + o, s + 2 * b, b, hipMemcpyDeviceToDevice, c->stream));
     c->N += count;
+    c->lists_valid = false;
     c->have_keys = c->have_prefix = c->sorted = false;
     c->n_dyn_host = -1;
     return 0;
@@ -722,6 +731,166 @@ int32_t sph_upload_rest_positions(SphContext* c, const int32_t* pid, const float
         int rc = sphk_scatter_rest(c, dpid, dx0, m);
         if (rc) return rc;
         SPH_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// DFSPH (DFSPH.py)
+// ---------------------------------------------------------------------------------------------
+int32_t sph_dfsph_set_params(SphContext* c, const SphDfsphParams* p) {
+    if (!c || !p) return SPH_E_INVALID;
+    if (p->m_max_iterations_v < 0 || p->m_max_iterations < 0 || p->fluid_particle_num < 0)
+        return sph_fail(c, SPH_E_INVALID, "sph_dfsph_set_params: negative count");
+    c->df = *p;
+    return 0;
+}
+
+int32_t sph_dfsph_get_stats(SphContext* c, SphDfsphStats* out) {
+    if (!c || !out) return SPH_E_INVALID;
+    *out = c->df_stats;
+    return 0;
+}
+
+#define DF_SWEEP(NAME, MODE)                         \
+    int32_t NAME(SphContext* c) {                    \
+        ENTER(c);                                    \
+        int rc = need_sorted(c, #NAME);              \
+        rc = rc ? rc : refresh_dyn(c);               \
+        return rc ? rc : sphk_gather(c, MODE);       \
+    }
+DF_SWEEP(sph_dfsph_compute_densities, GM_DF_DENSITY)
+DF_SWEEP(sph_dfsph_compute_DFSPH_factor, GM_DF_FACTOR)
+DF_SWEEP(sph_dfsph_compute_density_change, GM_DF_DENSITY_CHANGE)
+DF_SWEEP(sph_dfsph_compute_density_adv, GM_DF_DENSITY_ADV)
+DF_SWEEP(sph_dfsph_divergence_solver_iteration_kernel, GM_DF_DIV_ITER)
+DF_SWEEP(sph_dfsph_pressure_solve_iteration_kernel, GM_DF_PRESSURE_ITER)
+DF_SWEEP(sph_dfsph_compute_non_pressure_forces, GM_DF_NONPRESSURE)
+#undef DF_SWEEP
+
+int32_t sph_dfsph_compute_density_error(SphContext* c, float offset, float* out) {
+    ENTER(c);
+    if (!out) return SPH_E_INVALID;
+    return sphk_df_density_error(c, offset, out);
+}
+
+int32_t sph_dfsph_multiply_time_step(SphContext* c, float time_step) {
+    ENTER(c);
+    return sphk_df_scale_factor(c, time_step);
+}
+
+int32_t sph_dfsph_predict_velocity(SphContext* c) {
+    ENTER(c);
+    return sphk_df_predict_velocity(c);
+}
+
+int32_t sph_dfsph_advect(SphContext* c) {
+    ENTER(c);
+    return sphk_df_advect(c, false);
+}
+
+static int df_fluid_count(SphContext* c) { return c->df.fluid_particle_num > 0 ? c->df.fluid_particle_num : 1; }
+
+// DFSPH.py:240-283.  Host arithmetic in double, like the reference's Python floats.
+int32_t sph_dfsph_divergence_solve(SphContext* c) {
+    ENTER(c);
+    int rc = need_sorted(c, "sph_dfsph_divergence_solve");
+    rc = rc ? rc : refresh_dyn(c);
+    rc = rc ? rc : sphk_gather(c, GM_DF_DENSITY_CHANGE);
+    if (rc) return rc;
+    const double dt = (double)c->p.dt;
+    const double inv_dt = 1 / dt;
+    rc = sphk_df_scale_factor(c, (float)inv_dt);
+    if (rc) return rc;
+    int m_iterations_v = 0;
+    double avg_density_err = 0.0;
+    while (m_iterations_v < 1 || m_iterations_v < c->df.m_max_iterations_v) {
+        float density_err = 0.0f;
+        rc = sphk_gather(c, GM_DF_DIV_ITER);                     // divergence_solver_iteration(): kernel,
+        rc = rc ? rc : sphk_gather(c, GM_DF_DENSITY_CHANGE);     //   compute_density_change(),
+        rc = rc ? rc : sphk_df_density_error(c, 0.0f, &density_err);  // compute_density_error(0.0)
+        if (rc) return rc;
+        c->df_stats.total_iterations_v++;
+        avg_density_err = (double)density_err / df_fluid_count(c);
+        const double eta = 1.0 / dt * c->df.max_error_V * 0.01 * (double)c->p.density_0;
+        if (avg_density_err <= eta) break;
+        m_iterations_v += 1;
+    }
+    c->df_stats.iterations_v = m_iterations_v;
+    c->df_stats.avg_density_err_v = avg_density_err;
+    return sphk_df_scale_factor(c, (float)dt);
+}
+
+// DFSPH.py:324-354
+int32_t sph_dfsph_pressure_solve(SphContext* c) {
+    ENTER(c);
+    int rc = need_sorted(c, "sph_dfsph_pressure_solve");
+    rc = rc ? rc : refresh_dyn(c);
+    if (rc) return rc;
+    const double dt = (double)c->p.dt;
+    const double inv_dt2 = 1 / (dt * dt);
+    rc = sphk_gather(c, GM_DF_DENSITY_ADV);
+    rc = rc ? rc : sphk_df_scale_factor(c, (float)inv_dt2);
+    if (rc) return rc;
+    int m_iterations = 0;
+    double avg_density_err = 0.0;
+    while (m_iterations < 1 || m_iterations < c->df.m_max_iterations) {
+        float density_err = 0.0f;
+        rc = sphk_gather(c, GM_DF_PRESSURE_ITER);
+        rc = rc ? rc : sphk_gather(c, GM_DF_DENSITY_ADV);
+        rc = rc ? rc : sphk_df_density_error(c, c->p.density_0, &density_err);
+        if (rc) return rc;
+        c->df_stats.total_iterations++;
+        avg_density_err = (double)density_err / df_fluid_count(c);
+        const double eta = c->df.max_error * 0.01 * (double)c->p.density_0;
+        if (avg_density_err <= eta) break;
+        m_iterations += 1;
+    }
+    c->df_stats.iterations = m_iterations;
+    c->df_stats.avg_density_err = avg_density_err;
+    return 0;
+}
+
+int32_t sph_dfsph_step(SphContext* c, int32_t n_steps, const int32_t* dynamic_ids, int32_t n_dynamic) {
+    ENTER(c);
+    if (n_steps < 0 || n_dynamic < 0 || (n_dynamic > 0 && !dynamic_ids)) return sph_fail(c, SPH_E_INVALID, "sph_dfsph_step: bad arguments");
+    int rc = refresh_dyn(c);
+    if (rc) return rc;
+    const bool timing = c->opt_timing != 0;
+    for (int it = 0; it < n_steps; ++it) {
+        hipEvent_t* ev = nullptr;
+        if (timing) {
+            if (c->ev_used == SPH_MAX_TIMED_STEPS) { rc = harvest_events(c); if (rc) return rc; }
+            ev = c->ev[c->ev_used];
+            SPH_HIP(c, hipEventRecord(ev[0], c->stream));
+        }
+        rc = sph_update_grid_id(c);                                  // sph_base.py:264
+        rc = rc ? rc : sph_prefix_sum(c);
+        rc = rc ? rc : counting_sort(c, false);
+        if (rc) return rc;
+        if (timing) SPH_HIP(c, hipEventRecord(ev[1], c->stream));
+        if (c->n_dyn_host > 0) { rc = sphk_gather(c, GM_BVOL_DYNAMIC); if (rc) return rc; }  // sph_base.py:265
+        // DFSPHSolver.substep (DFSPH.py:400-408)
+        rc = sphk_gather(c, GM_DF_DENSITY);
+        rc = rc ? rc : sphk_gather(c, GM_DF_FACTOR);
+        if (rc) return rc;
+        if (timing) SPH_HIP(c, hipEventRecord(ev[2], c->stream));
+        if (c->df.enable_divergence_solver) { rc = sph_dfsph_divergence_solve(c); if (rc) return rc; }
+        rc = sphk_gather(c, GM_DF_NONPRESSURE);
+        rc = rc ? rc : sphk_df_predict_velocity(c);
+        rc = rc ? rc : sph_dfsph_pressure_solve(c);
+        if (rc) return rc;
+        if (timing) SPH_HIP(c, hipEventRecord(ev[3], c->stream));
+        rc = sphk_df_advect(c, true);                                // advect + enforce_boundary_3D(fluid)
+        if (rc) return rc;
+        if (c->n_dyn_host > 0)                                       // solve_rigid_body()  sph_base.py:247-260
+            for (int k = 0; k < n_dynamic; ++k) {
+                rc = sphk_rigid_solve(c, dynamic_ids[k]);
+                rc = rc ? rc : sphk_enforce_boundary(c, SPH_MATERIAL_SOLID);
+                if (rc) return rc;
+            }
+        if (timing) { SPH_HIP(c, hipEventRecord(ev[4], c->stream)); c->ev_used++; }
+        c->df_stats.steps++;
     }
     return 0;
 }

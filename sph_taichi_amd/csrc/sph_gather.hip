@@ -35,15 +35,21 @@ struct Target {
     float st_c;            // surface_tension / m_i
     float dpj_solid;       // p_i / rho0^2 (WCSPH.py:60)
     bool self_in_sum;      // density: the brick path sums the self pair (= m_V_i W(0)) with the neighbours
+    int nn;                // DFSPH.py:197 num_neighbors
 };
 
 template <int MODE>
+__host__ __device__ constexpr bool mode_is_df_iter() { return MODE == GM_DF_DIV_ITER || MODE == GM_DF_PRESSURE_ITER; }
+template <int MODE>
+__host__ __device__ constexpr bool mode_is_df_vdiv() { return MODE == GM_DF_DENSITY_CHANGE || MODE == GM_DF_DENSITY_ADV; }
+template <int MODE>
 __device__ __forceinline__ bool mode_needs_B() {
-    return MODE != GM_DENSITY && MODE != GM_DENSITY_EOS;
+    return MODE != GM_DENSITY && MODE != GM_DENSITY_EOS && MODE != GM_DF_DENSITY;
 }
 template <int MODE>
 __device__ __forceinline__ bool mode_needs_C() {
-    return MODE == GM_NONPRESSURE || MODE == GM_PRESSURE || MODE == GM_FORCE_FUSED;
+    return MODE == GM_NONPRESSURE || MODE == GM_PRESSURE || MODE == GM_FORCE_FUSED || mode_is_df_iter<MODE>() ||
+           MODE == GM_DF_NONPRESSURE;
 }
 
 // is particle (flags) a gather target of this mode?
@@ -70,7 +76,8 @@ __device__ __forceinline__ float4 make_C_from_aux(const float4 aux) {
 template <int MODE>
 __device__ __forceinline__ float4 target_load_E(const DevView& d, int i) {
     if (MODE == GM_NONPRESSURE || MODE == GM_PRESSURE) return d.aux[i];
-    if (MODE == GM_FORCE_FUSED) return d.eos[i];
+    if (MODE == GM_FORCE_FUSED || mode_is_df_iter<MODE>() || MODE == GM_DF_DENSITY_ADV || MODE == GM_DF_NONPRESSURE)
+        return d.eos[i];
     return make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
@@ -97,6 +104,22 @@ __device__ __forceinline__ void target_init(const DevView& d, Target& t, const f
         t.dpj_solid = t.p / (d.rho0 * d.rho0);
     }
     if (MODE == GM_BVOL_STATIC || MODE == GM_BVOL_DYNAMIC) t.s0 = d.w_zero;  // sph_base.py:95, 110
+    t.nn = 0;
+    // DFSPH: E = (dfsph_factor, density_adv, m, density)
+    if (MODE == GM_DF_FACTOR) t.ax = t.ay = t.az = 0.0f;  // grad_p_i (DFSPH.py:122)
+    if (MODE == GM_DF_DENSITY_ADV) t.rho = E.w;
+    if (MODE == GM_DF_DIV_ITER) {  // DFSPH.py:292-294: b_i = density_adv, k_i = b_i * factor; dv starts at 0
+        t.dpi = E.y * E.x; t.rho = E.w;
+        t.ax = t.ay = t.az = 0.0f;
+    }
+    if (MODE == GM_DF_PRESSURE_ITER) {  // DFSPH.py:362-363: b_i = density_adv - 1; v[p_i] is updated pair by pair
+        t.dpi = (E.y - 1.0f) * E.x; t.rho = E.w;
+        t.ax = B.x; t.ay = B.y; t.az = B.z;
+    }
+    if (MODE == GM_DF_NONPRESSURE) {
+        t.m = E.z; t.rho = E.w;
+        t.st_c = d.sigma / E.z;  // DFSPH.py:62
+    }
 }
 
 // Fast reciprocal / rsqrt (v_rsq_f32 / v_rcp_f32, ~1 ulp).  The reference's
@@ -120,6 +143,20 @@ __device__ __forceinline__ float sph_gradW_coef(const DevView& d, float q, float
     return r_norm > 1e-5f ? c * (rinv * d.inv_h) : 0.0f;
 }
 
+// particle_system.py:385: accept iff |x_i - x_j| < h (strict).  Every pair term vanishes continuously at r = h, so
+// the ~1 ulp of the fast rsqrt is immaterial -- except where neighbours are COUNTED (DFSPH.py:172-177 switches the
+// divergence source off below 20 neighbours): a rest lattice is full of pairs at exactly r = 2d = h, and there the
+// decision must be the correctly rounded sqrt's, like the oracle's.
+template <int MODE>
+__device__ __forceinline__ bool sph_within(const DevView& d, float r2, float rn) {
+    bool in = rn < d.h;
+    if (mode_is_df_vdiv<MODE>()) {
+        const float h2 = d.h * d.h;
+        if (fabsf(r2 - h2) <= 4e-6f * h2) in = __fsqrt_rn(r2) < d.h;
+    }
+    return in;
+}
+
 // One accepted pair (i != j, r_norm = |x_i - x_j| < h).  gj = global (sorted)
 // index of j, needed only for the coupling scatter.
 template <int MODE>
@@ -127,8 +164,8 @@ __device__ __forceinline__ void pair_physics(const DevView& d, Target& t, float 
                                              float r_norm, float rinv, const float4 A, const float4 B,
                                              const float4 Cc, int gj) {
     const float q = r_norm * d.inv_h;
-    if (MODE == GM_DENSITY || MODE == GM_DENSITY_EOS) {
-        // WCSPH.py:19-30: fluid and solid neighbours add m_V_j * W identically
+    if (MODE == GM_DENSITY || MODE == GM_DENSITY_EOS || MODE == GM_DF_DENSITY) {
+        // WCSPH.py:19-30 (= DFSPH.py:22-34): fluid and solid neighbours add m_V_j * W identically
         t.s0 += A.w * sph_W_q(d, q);
         return;
     }
@@ -139,6 +176,52 @@ __device__ __forceinline__ void pair_physics(const DevView& d, Target& t, float 
     }
     const bool j_fluid = sph_is_fluid(fj);
     const float gc = sph_gradW_coef(d, q, r_norm, rinv);
+    // ---- DFSPH: grad_p_j = -m_V_j gradW(x_i - x_j) = -(c rx, c ry, c rz) with c = m_V_j * gc ----
+    if (MODE == GM_DF_FACTOR) {
+        const float c = A.w * gc;
+        if (j_fluid) t.s0 += (c * c) * r2;           // DFSPH.py:145 sum_grad_p_k (fluid neighbours only)
+        t.ax += c * rx; t.ay += c * ry; t.az += c * rz;  // DFSPH.py:146-153 grad_p_i -= grad_p_j (both materials)
+        return;
+    }
+    if (mode_is_df_vdiv<MODE>()) {
+        // DFSPH.py:183-197 / :212-221: m_V_j (v_i - v_j) . gradW, fluid and boundary neighbours alike
+        t.s0 += A.w * (gc * ((t.vx - B.x) * rx + (t.vy - B.y) * ry + (t.vz - B.z) * rz));
+        t.nn += 1;
+        return;
+    }
+    if (mode_is_df_iter<MODE>()) {
+        const float off = (MODE == GM_DF_PRESSURE_ITER) ? 1.0f : 0.0f;
+        if (j_fluid) {
+            const float k_sum = t.dpi + (Cc.y - off) * Cc.x;  // DFSPH.py:299-301 / :370-372
+            if (fabsf(k_sum) > d.m_eps) {
+                const float c = (d.dt * k_sum) * (A.w * gc);  // dv -= dt k_sum grad_p_j
+                t.ax += c * rx; t.ay += c * ry; t.az += c * rz;
+            }
+        } else if (fabsf(t.dpi) > d.m_eps) {  // DFSPH.py:305-312 / :380-388 (Akinci boundary)
+            const float c = (d.dt * t.dpi) * (A.w * gc);  // vel_change = -dt k_i grad_p_j
+            const float fx = c * rx, fy = c * ry, fz = c * rz;
+            t.ax += fx; t.ay += fy; t.az += fz;
+            if (sph_is_dynamic_rigid(fj)) {  // DFSPH.py:313 / :389-390: -vel_change / dt * rho_i / rho_j
+                const float sc = t.rho * sph_rcp(Cc.w) * sph_rcp(d.dt);
+                float* a = reinterpret_cast<float*>(&d.acc[gj]);
+                unsafeAtomicAdd(a + 0, -fx * sc);
+                unsafeAtomicAdd(a + 1, -fy * sc);
+                unsafeAtomicAdd(a + 2, -fz * sc);
+            }
+        }
+        return;
+    }
+    if (MODE == GM_DF_NONPRESSURE) {
+        if (j_fluid) {  // DFSPH.py:53-83, the formulas of WCSPH.py:93-116; solid neighbours carry boundary_viscosity = 0
+            const float w = (r2 > d.d2) ? sph_W_q(d, q) : d.w_d;
+            const float c = t.st_c * Cc.z * w;
+            const float v_xy = (t.vx - B.x) * rx + (t.vy - B.y) * ry + (t.vz - B.z) * rz;
+            const float cv = d.visc_d_nu * (Cc.z * sph_rcp(Cc.w)) * v_xy * sph_rcp(r2 + d.visc_eps) * gc;
+            const float k = cv - c;
+            t.ax += k * rx; t.ay += k * ry; t.az += k * rz;
+        }
+        return;
+    }
     if (MODE == GM_NONPRESSURE || MODE == GM_FORCE_FUSED) {
         if (j_fluid) {
             // surface tension  WCSPH.py:93-102
@@ -205,10 +288,47 @@ __device__ __forceinline__ void target_finish(const DevView& d, Target& t, int i
         d.eos[i] = e;
         return;
     }
-    if (MODE == GM_NONPRESSURE) {
-        // WCSPH.py:130-140
+    if (MODE == GM_NONPRESSURE || MODE == GM_DF_NONPRESSURE) {
+        // WCSPH.py:130-140 / DFSPH.py:100-112
         if (sph_is_static_rigid(t.flags)) d.acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         else d.acc[i] = make_float4(t.ax, t.ay, t.az, 0.f);
+        return;
+    }
+    if (MODE == GM_DF_DENSITY) {  // DFSPH.py:42-47; eos = (factor, density_adv, m, density)
+        float4 aux = d.aux[i];
+        if (gathered) {
+            aux.y = (t.self_in_sum ? t.s0 : t.mV * d.w_zero + t.s0) * d.rho0;
+            reinterpret_cast<float*>(&d.aux[i])[1] = aux.y;
+        }
+        float* e = reinterpret_cast<float*>(&d.eos[i]);  // .x/.y (factor, density_adv) live until they are recomputed
+        e[2] = aux.x; e[3] = aux.y;
+        return;
+    }
+    if (MODE == GM_DF_FACTOR) {  // DFSPH.py:128-139
+        if (gathered) {
+            const float sum_grad_p_k = t.s0 + (t.ax * t.ax + t.ay * t.ay + t.az * t.az);
+            reinterpret_cast<float*>(&d.eos[i])[0] = sum_grad_p_k > 1e-6f ? -1.0f / sum_grad_p_k : 0.0f;
+        }
+        return;
+    }
+    if (MODE == GM_DF_DENSITY_CHANGE) {  // DFSPH.py:165-180
+        if (gathered) {
+            float adv = fmaxf(t.s0, 0.0f);
+            if (t.nn < 20) adv = 0.0f;
+            reinterpret_cast<float*>(&d.eos[i])[1] = adv;
+        }
+        return;
+    }
+    if (MODE == GM_DF_DENSITY_ADV) {  // DFSPH.py:206-209
+        if (gathered) reinterpret_cast<float*>(&d.eos[i])[1] = fmaxf(t.rho / d.rho0 + d.dt * t.s0, 1.0f);
+        return;
+    }
+    if (mode_is_df_iter<MODE>()) {  // DFSPH.py:296 v += dv  /  :378, :387 v updated in place (t.a started at v)
+        if (gathered) {
+            float* v = reinterpret_cast<float*>(&d.vf[i]);  // .w (flags) is read concurrently by other lanes
+            if (MODE == GM_DF_DIV_ITER) { v[0] = t.vx + t.ax; v[1] = t.vy + t.ay; v[2] = t.vz + t.az; }
+            else { v[0] = t.ax; v[1] = t.ay; v[2] = t.az; }
+        }
         return;
     }
     if (MODE == GM_PRESSURE) {
@@ -230,7 +350,7 @@ __device__ __forceinline__ void target_finish(const DevView& d, Target& t, int i
 
 template <int MODE>
 __device__ __forceinline__ float4 load_C_global(const DevView& d, int j) {
-    if (MODE == GM_FORCE_FUSED) return d.eos[j];
+    if (MODE == GM_FORCE_FUSED || mode_is_df_iter<MODE>() || MODE == GM_DF_NONPRESSURE) return d.eos[j];
     if (MODE == GM_NONPRESSURE || MODE == GM_PRESSURE) return make_C_from_aux<MODE>(d.aux[j]);
     return make_float4(0.f, 0.f, 0.f, 0.f);
 }
@@ -263,7 +383,7 @@ __device__ __forceinline__ void gather_walk_global(const DevView& d, Target& t, 
                 const float r2 = rx * rx + ry * ry + rz * rz;
                 const float rinv = sph_rsq(r2);
                 const float rn = r2 * rinv;
-                if (rn < d.h) {  // particle_system.py:385
+                if (sph_within<MODE>(d, r2, rn)) {  // particle_system.py:385
                     float4 B = make_float4(0.f, 0.f, 0.f, 0.f), Cc = B;
                     if (mode_needs_B<MODE>()) B = d.vf[j];
                     if (mode_needs_C<MODE>()) Cc = load_C_global<MODE>(d, j);
@@ -342,12 +462,14 @@ __global__ __launch_bounds__(TPB) void k_gather_bvol_split(DevView d, const int*
 #define SPH_CNT_WALK 255  // gcnt sentinel: this target must take the exact global cell walk
 
 template <int MODE>
-__host__ __device__ constexpr bool mode_writes_list() { return MODE == GM_DENSITY_EOS; }
+__host__ __device__ constexpr bool mode_writes_list() { return MODE == GM_DENSITY_EOS || MODE == GM_DF_DENSITY; }
 template <int MODE>
-__host__ __device__ constexpr bool mode_reads_list() { return MODE == GM_FORCE_FUSED; }
+__host__ __device__ constexpr bool mode_reads_list() { return MODE == GM_FORCE_FUSED || MODE >= GM_DF_FACTOR; }
 // sweeps whose pair term needs only (r, m_V_j): evaluated inside the filter's emission loop
 template <int MODE>
-__host__ __device__ constexpr bool mode_inline_physics() { return MODE == GM_DENSITY || MODE == GM_DENSITY_EOS; }
+__host__ __device__ constexpr bool mode_inline_physics() {
+    return MODE == GM_DENSITY || MODE == GM_DENSITY_EOS || MODE == GM_DF_DENSITY;
+}
 
 template <int BX_, int BY_, int BZ_, int CAP_, int LISTCAP_>
 struct BrickCfg {
@@ -514,7 +636,7 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
                     sQ[idx] = make_float4(-2.0f * xl, -2.0f * yl, -2.0f * zl, xl * xl + yl * yl + zl * zl);
                     sW[idx] = buf[u].w;
                 } else {
-                    sQ[idx] = make_float4(-2.0f * xl, -2.0f * yl, -2.0f * zl, buf[u].w);
+                    sQ[idx] = buf[u];  // list-reading sweeps: the record as it is, so x_i - x_j is the reference's own f32 difference
                 }
             }
         }
@@ -636,13 +758,14 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
             if (cnt > 0) {
                 jn = e1 & 2047;
                 const int c2 = e1 >> 11;
-                An = sQ[jn];  // (-2x', -2y', -2z', m_V)
+                An = sQ[jn];  // list-reading sweeps: (x, y, z, m_V)
                 if (HAS_W) An.w = sW[jn];
                 gn = sColG[c2] + (jn - sColS[c2]);
                 if (mode_needs_B<MODE>()) Bn = d.vf[gn];
                 if (mode_needs_C<MODE>()) Cn = load_C_global<MODE>(d, gn);
             }
             const float txl = t.x - Ox, tyl = t.y - Oy, tzl = t.z - Oz;
+            (void)txl; (void)tyl; (void)tzl;
             for (int k = 0; k < cnt; ++k) {
                 const float4 A = An;
                 const float4 B = Bn, Cc = Cn;
@@ -657,12 +780,14 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
                     if (mode_needs_C<MODE>()) Cn = load_C_global<MODE>(d, gn);
                     if (k + 2 < cnt) e2 = glist[(size_t)(k + 2) * cap + gi];
                 }
-                // x_i' - x_j' with x_j' = -A/2 (exact): the same difference as x_i - x_j
-                const float rx = fmaf(0.5f, A.x, txl), ry = fmaf(0.5f, A.y, tyl), rz = fmaf(0.5f, A.z, tzl);
+                // filtering sweeps hold x_j' = -A/2 in shell-local coordinates; list-reading sweeps hold x_j itself
+                const float rx = HAS_W ? fmaf(0.5f, A.x, txl) : t.x - A.x;
+                const float ry = HAS_W ? fmaf(0.5f, A.y, tyl) : t.y - A.y;
+                const float rz = HAS_W ? fmaf(0.5f, A.z, tzl) : t.z - A.z;
                 const float r2 = rx * rx + ry * ry + rz * rz;
                 const float rinv = sph_rsq(r2);
                 const float rn = r2 * rinv;
-                if (rn < d.h && j != li)  // particle_system.py:385
+                if (sph_within<MODE>(d, r2, rn) && j != li)  // particle_system.py:385
                     pair_physics<MODE>(d, t, rx, ry, rz, r2, rn, rinv, A, B, Cc, gj);
             }
         }
@@ -756,7 +881,21 @@ template <int MODE>
 static int launch_sweep(SphContext* c) {
     if (c->N <= 0) return 0;
     if (c->opt_gather_impl == 0) return launch_simple<MODE>(c, nullptr, c->N);
-    return launch_brick<MODE>(c);
+    int rc = launch_brick<MODE>(c);
+    if (!rc && mode_writes_list<MODE>()) c->lists_valid = true;
+    return rc;
+}
+
+// DFSPH sweeps: one brick shape (the lists of GM_DF_DENSITY are read back by every later sweep of the step, so
+// writer and readers must agree on it); a list-reading sweep called while the lists are stale (positions moved
+// since the density sweep: only possible through the stand-alone API calls) takes the exact cell walk instead.
+template <int MODE>
+static int launch_df(SphContext* c) {
+    if (c->N <= 0) return 0;
+    if (c->opt_gather_impl == 0 || (mode_reads_list<MODE>() && !c->lists_valid)) return launch_simple<MODE>(c, nullptr, c->N);
+    int rc = launch_brick_cfg<MODE, Cfg0>(c);
+    if (!rc && mode_writes_list<MODE>()) c->lists_valid = true;
+    return rc;
 }
 
 int sphk_gather(SphContext* c, int mode) {
@@ -775,6 +914,13 @@ int sphk_gather(SphContext* c, int mode) {
         case GM_NONPRESSURE: return launch_sweep<GM_NONPRESSURE>(c);
         case GM_PRESSURE: return launch_sweep<GM_PRESSURE>(c);
         case GM_FORCE_FUSED: return launch_sweep<GM_FORCE_FUSED>(c);
+        case GM_DF_DENSITY: return launch_df<GM_DF_DENSITY>(c);
+        case GM_DF_FACTOR: return launch_df<GM_DF_FACTOR>(c);
+        case GM_DF_DENSITY_CHANGE: return launch_df<GM_DF_DENSITY_CHANGE>(c);
+        case GM_DF_DENSITY_ADV: return launch_df<GM_DF_DENSITY_ADV>(c);
+        case GM_DF_DIV_ITER: return launch_df<GM_DF_DIV_ITER>(c);
+        case GM_DF_PRESSURE_ITER: return launch_df<GM_DF_PRESSURE_ITER>(c);
+        case GM_DF_NONPRESSURE: return launch_df<GM_DF_NONPRESSURE>(c);
     }
     return sph_fail(c, SPH_E_INVALID, "unknown gather mode");
 }

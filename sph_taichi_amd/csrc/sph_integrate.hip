@@ -55,6 +55,66 @@ __global__ __launch_bounds__(TPB) void k_advect(DevView d, WallHi hi) {
     d.vf[i] = vf;
 }
 
+// ---- DFSPH element-wise kernels (eos record = (dfsph_factor, density_adv, m, density)) ----
+// DFSPH.py:388-394 predict_velocity
+__global__ __launch_bounds__(TPB) void k_df_predict_velocity(DevView d) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= d.N) return;
+    float4 vf = d.vf[i];
+    const int fl = __float_as_int(vf.w);
+    if (!(sph_flags_dynamic(fl) && sph_is_fluid(fl))) return;
+    const float4 a = d.acc[i];
+    vf.x += d.dt * a.x; vf.y += d.dt * a.y; vf.z += d.dt * a.z;
+    d.vf[i] = vf;
+}
+
+// DFSPH.py:100-107 advect (only dynamic rigid particles integrate their acceleration here) + the fluid wall pass of
+// sph_base.py:270-271, which commutes with the rigid solve in between
+template <bool FLUID_WALLS>
+__global__ __launch_bounds__(TPB) void k_df_advect(DevView d, WallHi hi) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= d.N) return;
+    float4 vf = d.vf[i];
+    const int fl = __float_as_int(vf.w);
+    if (!sph_flags_dynamic(fl)) return;
+    float4 xm = d.xm[i];
+    if (sph_is_dynamic_rigid(fl)) {
+        const float4 a = d.acc[i];
+        vf.x += d.dt * a.x; vf.y += d.dt * a.y; vf.z += d.dt * a.z;
+    }
+    xm.x += d.dt * vf.x; xm.y += d.dt * vf.y; xm.z += d.dt * vf.z;
+    if (FLUID_WALLS && sph_is_fluid(fl)) wall_collide(d, hi.v, xm, vf);
+    d.xm[i] = xm;
+    d.vf[i] = vf;
+}
+
+// DFSPH.py:233-237 multiply_time_step(dfsph_factor, s)
+__global__ __launch_bounds__(TPB) void k_df_scale_factor(DevView d, float s) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= d.N) return;
+    if (!sph_is_fluid(__float_as_int(d.vf[i].w))) return;
+    float* e = reinterpret_cast<float*>(&d.eos[i]);
+    e[0] *= s;
+}
+
+// DFSPH.py:224-230 compute_density_error: sum over fluid of density_0 * density_adv - offset (f64 partials, one
+// atomic per workgroup; the reference's f32 reduction order is scheduling-dependent anyway)
+__global__ __launch_bounds__(TPB) void k_df_density_error(DevView d, float offset, double* __restrict__ out) {
+    __shared__ double red[TPB / 64];
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    double v = 0.0;
+    if (i < d.N && sph_is_fluid(__float_as_int(d.vf[i].w))) v = (double)(d.rho0 * d.eos[i].y - offset);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < TPB / 64; ++w) t += red[w];
+        atomicAdd(out, t);
+    }
+}
+
 // Slab halo packer: records [first, first+count) AS THEY WILL BE after this step's advect, written to dst
 // (count xm, then count vf, then count aux) without touching the arrays -- the interior force sweep that runs
 // concurrently with the exchange still needs the old positions; k_advect later repeats the same update in place.
@@ -454,6 +514,8 @@ __global__ __launch_bounds__(TPB) void k_extract(DevView d, int field, const int
         case SPH_F_IS_DYNAMIC: oi[i] = sph_flags_dynamic(fl); break;
         case SPH_F_GRID_IDS: oi[i] = d.key[i]; break;
         case SPH_F_PID: oi[i] = pid; break;
+        case SPH_F_DFSPH_FACTOR: of[i] = d.eos[i].x; break;
+        case SPH_F_DENSITY_ADV: of[i] = d.eos[i].y; break;
         default: break;
     }
 }
@@ -484,6 +546,8 @@ __global__ __launch_bounds__(TPB) void k_insert(DevView d, int field, float* __r
         case SPH_F_COLOR: for (int k = 0; k < 3; ++k) color_cold[3 * pid + k] = n[3 * i + k]; break;
         case SPH_F_IS_DYNAMIC: fl = (fl & ~0x100) | (n[i] ? 0x100 : 0); vf[3] = __int_as_float(fl); break;
         case SPH_F_PID: aux[3] = __int_as_float(n[i]); break;
+        case SPH_F_DFSPH_FACTOR: reinterpret_cast<float*>(&d.eos[i])[0] = f[i]; break;
+        case SPH_F_DENSITY_ADV: reinterpret_cast<float*>(&d.eos[i])[1] = f[i]; break;
         default: break;
     }
 }
@@ -509,6 +573,7 @@ int sphk_advect(SphContext* c, bool fused_fluid_walls) {
     if (fused_fluid_walls) hipLaunchKernelGGL(k_advect<true>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c));
     else hipLaunchKernelGGL(k_advect<false>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c));
     SPH_LAUNCH_CHECK(c);
+    c->lists_valid = false;
     return 0;
 }
 
@@ -522,6 +587,7 @@ int sphk_pack_advected(SphContext* c, int first, int count, void* dst) {
 }
 
 int sphk_enforce_boundary(SphContext* c, int particle_type) {
+    c->lists_valid = false;
     if (c->N <= 0) return 0;
     DevView d = sph_view(c);
     if (particle_type == SPH_MATERIAL_SOLID) {
@@ -554,6 +620,7 @@ int sphk_rigid_com(SphContext* c, int object_id, bool to_rest) {
 
 // solve_constraints (sph_base.py:200-222) without any host round trip: 3 launches, no atomics
 int sphk_rigid_solve(SphContext* c, int object_id) {
+    c->lists_valid = false;
     if (c->n_dyn_host <= 0) return 0;
     DevView d = sph_view(c);
     const int n = c->n_dyn_host, nb = (n + TPB - 1) / TPB;
@@ -577,6 +644,7 @@ int sphk_extract(SphContext* c, int field, void* dst) {
 }
 
 int sphk_insert(SphContext* c, int field, const void* src) {
+    if (field == SPH_F_X || field == SPH_F_MATERIAL || field == SPH_F_IS_DYNAMIC) c->lists_valid = false;
     if (c->N <= 0) return 0;
     DevView d = sph_view(c);
     hipLaunchKernelGGL(k_insert, dim3((c->N + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, field, c->x0_cold,
@@ -619,6 +687,7 @@ int sphk_rigid_partial16(SphContext* c, int object_id, int first, int count, dou
 }
 
 int sphk_rigid_apply16(SphContext* c, int object_id, const double* sums, int mode) {
+    c->lists_valid = false;
     DevView d = sph_view(c);
     const int n = c->n_dyn_host;
     const int nb = (mode == 1 && n > 0) ? (n + TPB - 1) / TPB : 1;
@@ -632,5 +701,47 @@ int sphk_scatter_rest(SphContext* c, const int* pid_dev, const float* x0_dev, in
     hipLaunchKernelGGL(k_scatter_rest, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, c->stream, c->x0_cold, pid_dev, x0_dev, n,
                        c->cold_cap);
     SPH_LAUNCH_CHECK(c);
+    return 0;
+}
+
+// ---- DFSPH element-wise launchers ----
+int sphk_df_predict_velocity(SphContext* c) {
+    if (c->N <= 0) return 0;
+    DevView d = sph_view(c);
+    hipLaunchKernelGGL(k_df_predict_velocity, dim3((c->N + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d);
+    SPH_LAUNCH_CHECK(c);
+    return 0;
+}
+
+int sphk_df_advect(SphContext* c, bool fused_fluid_walls) {
+    if (c->N <= 0) return 0;
+    DevView d = sph_view(c);
+    const int nb = (c->N + TPB - 1) / TPB;
+    if (fused_fluid_walls) hipLaunchKernelGGL(k_df_advect<true>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c));
+    else hipLaunchKernelGGL(k_df_advect<false>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c));
+    SPH_LAUNCH_CHECK(c);
+    c->lists_valid = false;
+    return 0;
+}
+
+int sphk_df_scale_factor(SphContext* c, float s) {
+    if (c->N <= 0) return 0;
+    DevView d = sph_view(c);
+    hipLaunchKernelGGL(k_df_scale_factor, dim3((c->N + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, s);
+    SPH_LAUNCH_CHECK(c);
+    return 0;
+}
+
+int sphk_df_density_error(SphContext* c, float offset, float* out_host) {
+    double h = 0.0;
+    if (c->N > 0) {
+        DevView d = sph_view(c);
+        SPH_HIP(c, hipMemsetAsync(c->df_err, 0, sizeof(double), c->stream));
+        hipLaunchKernelGGL(k_df_density_error, dim3((c->N + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, offset, c->df_err);
+        SPH_LAUNCH_CHECK(c);
+        SPH_HIP(c, hipMemcpyAsync(&h, c->df_err, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        SPH_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    *out_host = (float)h;
     return 0;
 }

@@ -38,6 +38,7 @@ struct DevView {
     float pad;
     float k_w, k_dw, visc_d_nu, visc_eps;
     float w_zero, w_d;  // W(0), W(d)
+    float m_eps;        // DFSPH.py:17
     float4* xm;
     float4* vf;
     float4* aux;
@@ -94,6 +95,10 @@ struct SphContext {
     void* stage;       // upload/download staging, cap*16 bytes (>= G*4)
     size_t stage_bytes;
     bool have_keys, have_prefix, sorted;
+    bool lists_valid;   // glist/gcnt describe the CURRENT positions and order (written by a list-writing brick sweep)
+    SphDfsphParams df;  // DFSPH solver knobs
+    SphDfsphStats df_stats;
+    double* df_err;     // device accumulator of compute_density_error
     // options
     int opt_gather_impl, opt_timing, opt_fused, opt_brick_shape, opt_no_dynamic, opt_ablate, opt_drop_outside;
     // timing
@@ -129,6 +134,10 @@ int sphk_gather(SphContext* c, int mode);
 int sphk_gather_layers(SphContext* c, int mode, int lo, int hi, int lo2, int hi2);  // brick sweep, targets in x layers [lo,hi) u [lo2,hi2)
 int sphk_pack_advected(SphContext* c, int first, int count, void* dst);
 int sphk_eos(SphContext* c);
+int sphk_df_density_error(SphContext* c, float offset, float* out_host);
+int sphk_df_scale_factor(SphContext* c, float s);
+int sphk_df_predict_velocity(SphContext* c);
+int sphk_df_advect(SphContext* c, bool fused_fluid_walls);
 int sphk_advect(SphContext* c, bool fused_fluid_walls);
 int sphk_enforce_boundary(SphContext* c, int particle_type);
 int sphk_rigid_com(SphContext* c, int object_id, bool to_rest);
@@ -143,7 +152,15 @@ enum GatherMode {
     GM_DENSITY_EOS = 3,   // + EOS (WCSPH.py:74-76), eos record, acc init of solids (fused step)
     GM_NONPRESSURE = 4,   // WCSPH.py:128-140
     GM_PRESSURE = 5,      // WCSPH.py:77-85 (second loop; EOS done by sphk_eos)
-    GM_FORCE_FUSED = 6    // K6 + K7 in one sweep (needs GM_DENSITY_EOS before)
+    GM_FORCE_FUSED = 6,   // K6 + K7 in one sweep (needs GM_DENSITY_EOS before)
+    // ---- DFSPH (DFSPH.py); eos record = (dfsph_factor, density_adv, m, density) ----
+    GM_DF_DENSITY = 7,         // DFSPH.py:37-47 (+ neighbour lists for every later sweep of the step)
+    GM_DF_FACTOR = 8,          // DFSPH.py:116-154
+    GM_DF_DENSITY_CHANGE = 9,  // DFSPH.py:157-197
+    GM_DF_DENSITY_ADV = 10,    // DFSPH.py:200-221
+    GM_DF_DIV_ITER = 11,       // DFSPH.py:285-321
+    GM_DF_PRESSURE_ITER = 12,  // DFSPH.py:356-394
+    GM_DF_NONPRESSURE = 13     // DFSPH.py:49-97
 };
 
 #ifdef __HIPCC__

@@ -88,6 +88,9 @@ class ParticleSystem:
         self.is_dynamic = mk(F.F_IS_DYNAMIC, np.int32, name="is_dynamic")
         self.grid_ids = mk(F.F_GRID_IDS, np.int32, w=False, name="grid_ids")
         self.pid = mk(F.F_PID, np.int32, name="pid")
+        if self.simulation_method == 4:                       # particle_system.py:115-117
+            self.dfsph_factor = mk(F.F_DFSPH_FACTOR, np.float32, name="dfsph_factor")
+            self.density_adv = mk(F.F_DENSITY_ADV, np.float32, name="density_adv")
         G = int(np.prod(self._local_grid_num))
         self.grid_particles_num = DeviceField(self, F.F_GRID_PARTICLES_NUM, np.int32, lambda: G, 0, False,
                                               "grid_particles_num")
@@ -187,6 +190,11 @@ class ParticleSystem:
         if solver_type == 0:
             from .WCSPH import WCSPHSolver
             return WCSPHSolver(self)
+        if solver_type == 4:
+            if self.slab is not None:
+                raise NotImplementedError("DFSPH is single-GPU (its solver loops need a global density error)")
+            from .DFSPH import DFSPHSolver
+            return DFSPHSolver(self)
         raise NotImplementedError(f"Solver type {solver_type} has not been implemented.")
 
     def update_grid_id(self):

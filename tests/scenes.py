@@ -80,6 +80,14 @@ def fluid_with_rigid_bodies(obj_path, fluid_velocity=(0.0, -1.0, 0.0)):
     return sd
 
 
+def as_dfsph(scene_dict, dt=0.002):
+    """The same scene under DFSPHSolver (simulationMethod 4, DFSPH.py)."""
+    sd = copy.deepcopy(scene_dict)
+    sd["Configuration"]["simulationMethod"] = 4
+    sd["Configuration"]["timeStepSize"] = dt
+    return sd
+
+
 def jitter(scene, amplitude=0.1, seed=0):
     """positions += U(-a d, a d): breaks lattice ties for sort / force tests."""
     rng = np.random.default_rng(seed)
@@ -99,7 +107,8 @@ def solver_params(cfg, scene):
     g = scene.geom
     return dict(particle_radius=g.particle_radius, domain_size=list(g.domain_size), density_0=cfg.get_cfg("density0"),
                 stiffness=cfg.get_cfg("stiffness"), exponent=cfg.get_cfg("exponent"),
-                dt=cfg.get_cfg("timeStepSize"), g=cfg.get_cfg("gravitation"))
+                dt=cfg.get_cfg("timeStepSize"), g=cfg.get_cfg("gravitation"),
+                simulation_method=cfg.get_cfg("simulationMethod") or 0, fluid_particle_num=scene.fluid_particle_num)
 
 
 def make_oracle(cfg, scene, omp_threads=1, rigid_sums_f64=False):

@@ -23,6 +23,18 @@ F_FIELDS = ["x", "x_0", "v", "acceleration", "m_V", "m", "density", "pressure"]
 KERNEL_STAGES = [("k_sort", "initialize_particle_system"), ("k_bvol", "compute_moving_boundary_volume"),
                  ("k_density", "compute_densities"), ("k_nonpressure", "compute_non_pressure_forces"),
                  ("k_pressure", "compute_pressure_forces"), ("k_advect", "advect")]
+# DFSPHSolver.substep unrolled (DFSPH.py:400-408); (stage, oracle method, solver method, DFSPH fields that are live)
+DFSPH_STAGES = [("k_sort", "initialize_particle_system", "initialize_particle_system", ()),
+                ("k_bvol", "compute_moving_boundary_volume", "compute_moving_boundary_volume", ()),
+                ("k_density", "compute_densities", "compute_densities", ()),
+                ("k_factor", "compute_DFSPH_factor", "compute_DFSPH_factor", ("dfsph_factor",)),
+                ("k_density_change", "compute_density_change", "compute_density_change", ("dfsph_factor", "density_adv")),
+                ("k_divergence", "divergence_solve", "divergence_solve", ("dfsph_factor", "density_adv")),
+                ("k_nonpressure", "compute_non_pressure_forces", "compute_non_pressure_forces", ("dfsph_factor",)),
+                ("k_predict", "predict_velocity", "predict_velocity", ("dfsph_factor",)),
+                ("k_density_adv", "compute_density_adv", "compute_density_adv", ("dfsph_factor", "density_adv")),
+                ("k_pressure_solve", "pressure_solve", "pressure_solve", ("dfsph_factor", "density_adv")),
+                ("k_advect", "dfsph_advect", "advect", ("dfsph_factor", "density_adv"))]
 
 
 def _load(path):
@@ -31,15 +43,20 @@ def _load(path):
     return z, sd, int(z["steps"])
 
 
-def _check(z, stage, get, f_tol, label):
+def _is_dfsph(sd):
+    return sd["Configuration"].get("simulationMethod") == 4
+
+
+def _check(z, stage, get, f_tol, label, extra=()):
     for f in INT_FIELDS:
         assert np.array_equal(get(f), z[f"{stage}/{f}"]), f"{label} {stage}/{f}"
-    for f in F_FIELDS:
+    for f in F_FIELDS + list(extra):
         ref = z[f"{stage}/{f}"]
         got = get(f)
         scale = max(float(np.abs(ref).max()), 1e-30)
         err = float(np.abs(got.astype(np.float64) - ref.astype(np.float64)).max()) / scale
-        assert err <= f_tol[f] if isinstance(f_tol, dict) else err <= f_tol, f"{label} {stage}/{f}: {err:.3e}"
+        lim = f_tol.get(f, f_tol.get("*")) if isinstance(f_tol, dict) else f_tol
+        assert err <= lim, f"{label} {stage}/{f}: {err:.3e}"
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
@@ -53,6 +70,26 @@ def test_oracle_reproduces_reference_execution(path):
     tol = 2e-6
     o.initialize()
     _check(z, "initialized", get, tol, "oracle")
+    if _is_dfsph(sd):
+        its = []
+        for stage, method, _, live in DFSPH_STAGES:
+            r = getattr(o, method)()
+            if method in ("divergence_solve", "pressure_solve"):
+                its.append(r)
+            _check(z, stage, get, tol, "oracle", ("dfsph_factor", "density_adv"))   # the oracle sorts them too
+        o.solve_rigid_body()
+        o.enforce_boundary_3D(1)
+        _check(z, "step1", get, tol, "oracle")
+        assert its == list(z["solver/iterations"][0]), "solver iteration counts differ from the reference run"
+        for s in range(2, steps + 1):
+            o.step(1)
+            # velocities / accelerations pass through several Jacobi sweeps of large cancelling pair terms: the
+            # few-ulp differences (libm powf vs numpy, 3-vector sum order) roughly triple per step in this
+            # violently compressing scene (every kernel of step 1 is pinned to 2e-6 above; iteration counts are exact)
+            _check(z, f"step{s}", get, {"*": 1e-3, "x": 5e-5, "m_V": 5e-6}, "oracle",
+                   ("dfsph_factor", "density_adv"))
+            assert [o.s.last_iterations_v, o.s.last_iterations] == list(z["solver/iterations"][s - 1])
+        return
     for stage, method in KERNEL_STAGES:
         getattr(o, method)()
         _check(z, stage, get, tol, "oracle")
@@ -75,9 +112,18 @@ def test_hip_reproduces_reference_execution(path, impl):
            "pressure": 5e-3}
     solver.initialize()
     _check(z, "initialized", get, tol, "hip")
-    for stage, method in KERNEL_STAGES:
-        getattr(solver if hasattr(solver, method) else ps, method)()
-        _check(z, stage, get, tol, "hip")
+    if _is_dfsph(sd):
+        # dfsph_factor is rescaled by 1/dt resp. 1/dt^2 inside the solves: compare relative to its own magnitude
+        tol = dict(tol, v=2e-5, acceleration=2e-3, dfsph_factor=5e-5, density_adv=2e-5)
+        for stage, _, method, live in DFSPH_STAGES:
+            getattr(solver if hasattr(solver, method) else ps, method)()
+            _check(z, stage, get, tol, "hip", live)
+        st = solver.stats()
+        assert [st["iterations_v"], st["iterations"]] == list(z["solver/iterations"][0])
+    else:
+        for stage, method in KERNEL_STAGES:
+            getattr(solver if hasattr(solver, method) else ps, method)()
+            _check(z, stage, get, tol, "hip")
     solver.solve_rigid_body()
     solver.enforce_boundary_3D(1)
     _check(z, "step1", get, tol, "hip")

@@ -234,3 +234,135 @@ def test_shape_matched_rigid_bodies(tmp_path, impl):
     assert v[sc.arrays["object_id"] == 1, 1].mean() > -2.0 - 9.81 * n * 4e-4 + 0.02, "body 1 never felt the fluid"
     assert np.allclose(solver.compute_com_kernel(2), x_ref[sc.arrays["object_id"] == 2].mean(axis=0), atol=1e-4)
     ps.close()
+
+
+# ---------------------------------------------------------------------------
+# DFSPH (simulationMethod 4, DFSPH.py) on the same machinery
+# ---------------------------------------------------------------------------
+DF_TOL = {"density": 2e-5, "dfsph_factor": 5e-5, "density_adv": 3e-5, "acceleration": 2e-3, "v": 3e-5, "x": 2e-6}
+
+
+def _dfsph_scene(moving=True):
+    sd = scenes.fluid_with_rigid_blocks(fluid_counts=(12, 12, 10), static_counts=(16, 2, 14), dyn_counts=(4, 4, 4))
+    if moving:
+        sd["FluidBlocks"][0]["velocity"] = [0.5, -1.0, 0.3]
+        sd["RigidBlocks"][1]["velocity"] = [0.0, -8.0, 0.0]      # the cube hits the fluid within a few steps
+    return scenes.as_dfsph(sd)
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+def test_dfsph_kernel_by_kernel(impl):
+    """Every kernel of DFSPHSolver.substep (DFSPH.py:400-408), HIP vs oracle, after two warm-up steps so that the
+    cube is in contact, densities exceed rho0 and both solvers have work."""
+    sd = _dfsph_scene()
+    cfg, sc = scenes.build(sd)
+    scenes.jitter(sc, 0.15, seed=3)
+    o = scenes.make_oracle(cfg, sc)
+    ps, solver = scenes.make_ps(sd, sc.arrays, gather_impl=impl)
+    o.initialize(); solver.initialize()
+    o.step(2); solver.step(2)
+    o.initialize_particle_system(); ps.initialize_particle_system()
+    assert np.array_equal(ps.pid.to_numpy(), o["pid"])
+    o.compute_moving_boundary_volume(); solver.compute_moving_boundary_volume()
+    stages = [("compute_densities", "compute_densities", ("density",)),
+              ("compute_DFSPH_factor", "compute_DFSPH_factor", ("dfsph_factor",)),
+              ("compute_density_change", "compute_density_change", ("density_adv",)),
+              ("divergence_solve", "divergence_solve", ("v", "density_adv", "dfsph_factor")),
+              ("compute_non_pressure_forces", "compute_non_pressure_forces", ("acceleration",)),
+              ("predict_velocity", "predict_velocity", ("v",)),
+              ("compute_density_adv", "compute_density_adv", ("density_adv",)),
+              ("pressure_solve", "pressure_solve", ("v", "density_adv", "acceleration")),
+              ("dfsph_advect", "advect", ("x", "v"))]
+    fluid = o["material"] == 1
+    for om, sm, fields in stages:
+        r = getattr(o, om)()
+        getattr(solver, sm)()
+        for f in fields:
+            got, ref = getattr(ps, f).to_numpy(), o[f]
+            if f in ("dfsph_factor", "density_adv"):          # defined on fluid particles only
+                got, ref = got[fluid], ref[fluid]
+            _cmp(f"{om}:{f}", got, ref, DF_TOL[f])
+        if om == "divergence_solve":
+            assert solver.stats()["iterations_v"] == r
+        if om == "pressure_solve":
+            assert solver.stats()["iterations"] == r
+    e0 = o.compute_density_error(0.0)
+    assert abs(solver.compute_density_error(0.0) - e0) <= 1e-4 * abs(e0) + 1e-2
+    ps.close()
+
+
+@pytest.mark.parametrize("impl", [0, 1])
+def test_dfsph_trajectory(impl):
+    sd = _dfsph_scene()
+    cfg, sc = scenes.build(sd)
+    scenes.jitter(sc, 0.1, seed=5)
+    o = scenes.make_oracle(cfg, sc)
+    ps, solver = scenes.make_ps(sd, sc.arrays, gather_impl=impl)
+    o.initialize(); solver.initialize()
+    n = 12
+    its = []
+    for _ in range(n):
+        o.step(1)
+        its.append((o.s.last_iterations_v, o.s.last_iterations))
+    solver.step(n)
+    x_ref, x = o.by_pid("x"), scenes.ps_by_pid(ps, "x")
+    err = scenes.rel_l2(x, x_ref)
+    assert err <= 1e-4, f"rel L2 position error after {n} DFSPH steps = {err:.3e}"
+    assert scenes.rel_l2(scenes.ps_by_pid(ps, "v"), o.by_pid("v")) <= 5e-3
+    st = solver.stats()
+    assert st["steps"] == n
+    # total solver work equals the oracle's (a borderline convergence test may shift one iteration)
+    assert abs(st["total_iterations_v"] - sum(a + 1 for a, _ in its)) <= 1
+    assert abs(st["total_iterations"] - sum(b + 1 for _, b in its)) <= 1
+    assert sum(a for a, _ in its) > 0, "the divergence solver never iterated: the scene does not test it"
+    dyn = (sc.arrays["material"] == 0) & (sc.arrays["is_dynamic"] == 1)
+    assert np.abs(scenes.ps_by_pid(ps, "v")[dyn, 1] + 8.0).max() > 0.05, "the cube never felt the fluid"
+    ps.close()
+
+
+def test_dfsph_reference_step_equals_fast_step_and_stale_lists():
+    """(1) SPHBase.step() through the individual DFSPH kernels == sph_dfsph_step(); (2) a list-reading sweep called
+    after the particles moved (lists stale) must fall back to the exact cell walk, not read the old lists."""
+    sd = _dfsph_scene()
+    cfg, sc = scenes.build(sd)
+    ps1, s1 = scenes.make_ps(sd, sc.arrays)
+    ps2, s2 = scenes.make_ps(sd, sc.arrays)
+    s1.initialize(); s2.initialize()
+    for _ in range(4):
+        s1._reference_step()
+    s2.step(4)
+    assert scenes.rel_l2(scenes.ps_by_pid(ps2, "x"), scenes.ps_by_pid(ps1, "x")) <= 1e-5
+    # stale lists: move the particles after the density sweep, then ask for the factor without a fresh one
+    from sph_taichi_amd import _lib
+    ps2.initialize_particle_system()
+    s2.compute_densities()
+    s2.advect()                                      # positions move, order unchanged: the lists are now stale
+    s2.compute_DFSPH_factor()                        # must NOT read them
+    f_brick = ps2.dfsph_factor.to_numpy()
+    ps2.set_option(_lib.OPT_GATHER_IMPL, 0)
+    s2.compute_DFSPH_factor()                        # exact cell walk on the same state
+    fluid = ps2.material.to_numpy() == 1
+    _cmp("stale-list factor", f_brick[fluid], ps2.dfsph_factor.to_numpy()[fluid], 1e-6)
+    ps1.close(); ps2.close()
+
+
+def test_dfsph_crowded_cell_overflow_paths():
+    """A crowded region (list overflow / LDS capacity overflow -> exact cell walk) under every DFSPH sweep."""
+    sd = scenes.as_dfsph(scenes.fluid_only(counts=(10, 10, 8), start=(0.1, 0.1, 0.1)))
+    cfg, sc = scenes.build(sd)
+    rng = np.random.default_rng(11)
+    x = sc.arrays["x"]
+    sel = rng.choice(x.shape[0], 90, replace=False)
+    x[sel] = np.float32([0.21, 0.21, 0.21]) + rng.uniform(0, 0.035, size=(90, 3)).astype(np.float32)
+    sc.arrays["x_0"] = x.copy()
+    o = scenes.make_oracle(cfg, sc)
+    ps, solver = scenes.make_ps(sd, sc.arrays)
+    o.initialize(); solver.initialize()
+    o.initialize_particle_system(); ps.initialize_particle_system()
+    for om, sm, f in (("compute_densities", "compute_densities", "density"),
+                      ("compute_DFSPH_factor", "compute_DFSPH_factor", "dfsph_factor"),
+                      ("compute_density_change", "compute_density_change", "density_adv"),
+                      ("compute_non_pressure_forces", "compute_non_pressure_forces", "acceleration")):
+        getattr(o, om)(); getattr(solver, sm)()
+        _cmp(f"crowded {om}", getattr(ps, f).to_numpy(), o[f], 5e-4)
+    ps.close()

@@ -146,7 +146,7 @@ __device__ __forceinline__ float sph_gradW_coef(const DevView& d, float q, float
 // particle_system.py:385: accept iff |x_i - x_j| < h (strict).  Every pair term vanishes continuously at r = h, so
 // the ~1 ulp of the fast rsqrt is immaterial -- except where neighbours are COUNTED (DFSPH.py:172-177 switches the
 // divergence source off below 20 neighbours): a rest lattice is full of pairs at exactly r = 2d = h, and there the
-// decision must be the correctly rounded sqrt's, like the oracle's.
+// decision must be the correctly rounded sqrt's (what a plain f32 evaluation of r.norm() < h gives).
 template <int MODE>
 __device__ __forceinline__ bool sph_within(const DevView& d, float r2, float rn) {
     bool in = rn < d.h;

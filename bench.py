@@ -51,7 +51,18 @@ WORKLOADS = {
 }
 
 
-def scene_dict(workload: str):
+DFSPH_DT = 0.004    # timeStepSize of every *_dfsph.json scene of the reference (data/scenes/)
+
+
+def scene_dict(workload: str, solver: str = "wcsph"):
+    sd = _scene_dict(workload)
+    if solver == "dfsph":
+        sd["Configuration"]["simulationMethod"] = 4
+        sd["Configuration"]["timeStepSize"] = DFSPH_DT
+    return sd
+
+
+def _scene_dict(workload: str):
     if workload in ("c2_dragon_bath", "c3_armadillo_equiv"):
         # the reference's two demo scenes with their bodies taken from the committed voxel fixtures
         # (tests/golden/*.npy; /root/reference does not exist on the GPU box)
@@ -79,7 +90,8 @@ def cpu_baseline(sd, sample_steps: int):
     g = sc.geom
     params = dict(particle_radius=g.particle_radius, domain_size=list(g.domain_size),
                   density_0=cfg.get_cfg("density0"), stiffness=cfg.get_cfg("stiffness"),
-                  exponent=cfg.get_cfg("exponent"), dt=cfg.get_cfg("timeStepSize"), g=cfg.get_cfg("gravitation"))
+                  exponent=cfg.get_cfg("exponent"), dt=cfg.get_cfg("timeStepSize"), g=cfg.get_cfg("gravitation"),
+                  simulation_method=cfg.get_cfg("simulationMethod") or 0, fluid_particle_num=sc.fluid_particle_num)
     threads = max_threads()
     o = Oracle(params, sc.arrays, n_objects=max(sc.n_objects, 1), rigid_body_ids=sorted(sc.object_id_rigid_body),
                dynamic_ids=sorted(sc.dynamic_rigid_ids), omp_threads=threads)
@@ -104,6 +116,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c3p_uniform_1.75M",
                     choices=sorted(WORKLOADS) + ["c2_dragon_bath", "c3_armadillo_equiv"])
+    ap.add_argument("--solver", default="wcsph", choices=["wcsph", "dfsph"],
+                    help="dfsph: the same workload under DFSPHSolver (simulationMethod 4, dt = 4e-3) -- a supplementary "
+                         "line, not BASELINE.json's metric")
     ap.add_argument("--gather-impl", type=int, default=1)
     ap.add_argument("--brick-shape", type=int, default=0)
     ap.add_argument("--fused", type=int, default=1)
@@ -140,7 +155,7 @@ def main():
         return
 
     from sph_taichi_amd import ParticleSystem, SimConfig, _lib
-    sd = scene_dict(args.workload)
+    sd = scene_dict(args.workload, args.solver)
     ps = ParticleSystem(SimConfig(config=copy.deepcopy(sd)), device=local_rank)
     solver = ps.build_solver()
     N = ps.particle_max_num
@@ -190,6 +205,34 @@ def main():
                   file=sys.stderr, flush=True)
         ps.set_option(_lib.OPT_DEBUG_ABLATE, 0)
         solver.dt[None] = CFG["timeStepSize"]
+    if args.solver == "dfsph":
+        it0 = solver.stats()
+        dt, tm = run(args.gather_impl, args.brick_shape, 1, args.steps, args.warmup)
+        it1 = solver.stats()
+        k = max(int(tm.steps), 1)
+        iv = (it1["total_iterations_v"] - it0["total_iterations_v"]) / (args.warmup + args.steps)
+        ip = (it1["total_iterations"] - it0["total_iterations"]) / (args.warmup + args.steps)
+        sweeps = 2 + (1 + 2 * iv) + 1 + (1 + 2 * ip)     # density, factor | divergence solve | forces | pressure solve
+        line = {
+            "metric": "DFSPH steps/sec at 1.74 M particles (supplementary; BASELINE.json's metric is the WCSPH step)",
+            "value": round(args.steps / dt * N / REF_PARTICLES, 3), "unit": "steps/s", "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "solver": "dfsph", "particles": N, "cells": G, "dt": DFSPH_DT,
+                       "gather_impl": args.gather_impl, "parallelism": "1 GPU"},
+            "breakdown_ms": {"sort": round(tm.sort_ms / k, 4), "neighbour": round(tm.neighbour_ms / k, 4),
+                             "force": round(tm.force_ms / k, 4), "integrate": round(tm.integrate_ms / k, 4),
+                             "sum_of_phases": round(tm.total_ms / k, 4)},
+            "dfsph": {"divergence_iterations_per_step": round(iv, 2), "pressure_iterations_per_step": round(ip, 2),
+                      "neighbour_sweeps_per_step": round(sweeps, 2),
+                      "ms_per_sweep": round((tm.neighbour_ms + tm.force_ms) / k / sweeps, 4),
+                      "simulated_time_per_wall_second": round(args.steps / dt * DFSPH_DT, 3)},
+            "roofline": None,
+        }
+        ps.close()
+        line["cpu_baseline"] = cpu_baseline(sd, args.cpu_steps) if args.cpu_steps > 0 else None
+        print(json.dumps(line), flush=True)
+        return
     dt, tm = run(args.gather_impl, args.brick_shape, args.fused, args.steps, args.warmup)
     k = max(int(tm.steps), 1)
     ms_per_step = dt / args.steps * 1e3

@@ -142,6 +142,8 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     rc = rc ? rc : alloc_dev(c, (void**)&c->rigid_part, (size_t)c->rigid_part_blocks * 16 * sizeof(double));
     rc = rc ? rc : alloc_dev(c, (void**)&c->rigid_R, 16 * sizeof(float));
     rc = rc ? rc : alloc_dev(c, (void**)&c->df_err, sizeof(double));
+    rc = rc ? rc : alloc_dev(c, (void**)&c->df_part, SPH_DF_ERR_BLOCKS * sizeof(double));
+    if (!rc && hipHostMalloc((void**)&c->h_df_err, sizeof(double), hipHostMallocMapped) != hipSuccess) rc = SPH_E_NOMEM;
     c->stage_bytes = cap * 16 > (size_t)c->G * 4 ? cap * 16 : (size_t)c->G * 4;
     rc = rc ? rc : alloc_dev(c, &c->stage, c->stage_bytes);
     if (!rc && hipHostMalloc((void**)&c->h_pinned, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess) rc = SPH_E_NOMEM;
@@ -158,7 +160,7 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
         return rc;
     }
     c->n_dyn_host = -1;  // unknown until material / is_dynamic are uploaded
-    c->lists_valid = false;
+    sph_invalidate_lists(c);
     memset(&c->df_stats, 0, sizeof(c->df_stats));
     c->df.enable_divergence_solver = 1; c->df.m_max_iterations_v = 100; c->df.m_max_iterations = 100;  // DFSPH.py:12-20
     c->df.fluid_particle_num = 0; c->df.m_eps = 1e-5f; c->df.reserved_ = 0.0f; c->df.max_error_V = 0.1; c->df.max_error = 0.05;
@@ -172,11 +174,12 @@ int32_t sph_destroy(SphContext* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->xm[0], c->xm[1], c->vf[0], c->vf[1], c->aux[0], c->aux[1], c->key[0], c->key[1], c->eos, c->acc,
                     c->acc_tmp, c->cell_end, c->rank_off, c->idx_unstable, c->scan_sums, c->x0_cold, c->color_cold,
-                    c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->rigid_part, c->rigid_R, c->df_err, c->stage, c->glist, c->gcnt, c->brick_list, c->brick_count};
+                    c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->rigid_part, c->rigid_R, c->df_err, c->df_part, c->stage, c->glist, c->gcnt, c->brick_list, c->brick_count};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < SPH_MAX_TIMED_STEPS; ++s)
         for (int k = 0; k < 5; ++k) if (c->ev[s][k]) (void)hipEventDestroy(c->ev[s][k]);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->h_df_err) (void)hipHostFree(c->h_df_err);
     if (c->ev_off) (void)hipEventDestroy(c->ev_off);
     if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -232,7 +235,7 @@ int32_t sph_set_particle_count(SphContext* c, int32_t n) {
     if (!c || n < 0 || n > c->cap) return sph_fail(c, SPH_E_INVALID, "particle count out of range");
     c->N = n;
     c->n_dyn_host = -1;
-    c->lists_valid = false;
+    sph_invalidate_lists(c);
     c->have_keys = c->have_prefix = false;
     return 0;
 }
@@ -576,7 +579,7 @@ int32_t sph_select_range(SphContext* c, int32_t first, int32_t count) {
     if (first < 0 || count < 0 || first + count > c->in_off + c->N) return sph_fail(c, SPH_E_INVALID, "sph_select_range: out of range");
     c->in_off += first;
     c->N = count;
-    c->lists_valid = false;
+    sph_invalidate_lists(c);
     c->have_keys = c->have_prefix = c->sorted = false;
     c->n_dyn_host = -1;
     return 0;
@@ -612,7 +615,7 @@ int32_t sph_append_records(SphContext* c, const void* src, int32_t count) {
     SPH_HIP(c, hipMemcpyAsync(c->vf[c->cur] + o, s + b, b, hipMemcpyDeviceToDevice, c->stream));
     SPH_HIP(c, hipMemcpyAsync(c->aux[c->cur] + o, s + 2 * b, b, hipMemcpyDeviceToDevice, c->stream));
     c->N += count;
-    c->lists_valid = false;
+    sph_invalidate_lists(c);
     c->have_keys = c->have_prefix = c->sorted = false;
     c->n_dyn_host = -1;
     return 0;

@@ -97,13 +97,14 @@ __global__ __launch_bounds__(TPB) void k_df_scale_factor(DevView d, float s) {
     e[0] *= s;
 }
 
-// DFSPH.py:224-230 compute_density_error: sum over fluid of density_0 * density_adv - offset (f64 partials, one
-// atomic per workgroup; the reference's f32 reduction order is scheduling-dependent anyway)
-__global__ __launch_bounds__(TPB) void k_df_density_error(DevView d, float offset, double* __restrict__ out) {
+// DFSPH.py:224-230 compute_density_error: sum over fluid of density_0 * density_adv - offset.  Two stages, f64
+// partials in a fixed order (the reference's f32 reduction order is scheduling-dependent anyway); the total lands
+// in pinned host memory, so the host only waits for the stream.
+__global__ __launch_bounds__(TPB) void k_df_density_error(DevView d, float offset, double* __restrict__ part) {
     __shared__ double red[TPB / 64];
-    const int i = blockIdx.x * TPB + threadIdx.x;
     double v = 0.0;
-    if (i < d.N && sph_is_fluid(__float_as_int(d.vf[i].w))) v = (double)(d.rho0 * d.eos[i].y - offset);
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < d.N; i += gridDim.x * TPB)
+        if (sph_is_fluid(__float_as_int(d.vf[i].w))) v += (double)(d.rho0 * d.eos[i].y - offset);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
@@ -111,8 +112,17 @@ __global__ __launch_bounds__(TPB) void k_df_density_error(DevView d, float offse
     if (threadIdx.x == 0) {
         double t = 0.0;
         for (int w = 0; w < TPB / 64; ++w) t += red[w];
-        atomicAdd(out, t);
+        part[blockIdx.x] = t;
     }
+}
+
+__global__ __launch_bounds__(64) void k_df_density_error_total(const double* __restrict__ part, int n,
+                                                               double* __restrict__ out) {
+    double v = 0.0;
+    for (int k = threadIdx.x; k < n; k += 64) v += part[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (threadIdx.x == 0) *out = v;
 }
 
 // Slab halo packer: records [first, first+count) AS THEY WILL BE after this step's advect, written to dst
@@ -573,7 +583,7 @@ int sphk_advect(SphContext* c, bool fused_fluid_walls) {
     if (fused_fluid_walls) hipLaunchKernelGGL(k_advect<true>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c));
     else hipLaunchKernelGGL(k_advect<false>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c));
     SPH_LAUNCH_CHECK(c);
-    c->lists_valid = false;
+    sph_invalidate_lists(c);
     return 0;
 }
 
@@ -587,7 +597,7 @@ int sphk_pack_advected(SphContext* c, int first, int count, void* dst) {
 }
 
 int sphk_enforce_boundary(SphContext* c, int particle_type) {
-    c->lists_valid = false;
+    sph_invalidate_lists(c);
     if (c->N <= 0) return 0;
     DevView d = sph_view(c);
     if (particle_type == SPH_MATERIAL_SOLID) {
@@ -620,7 +630,7 @@ int sphk_rigid_com(SphContext* c, int object_id, bool to_rest) {
 
 // solve_constraints (sph_base.py:200-222) without any host round trip: 3 launches, no atomics
 int sphk_rigid_solve(SphContext* c, int object_id) {
-    c->lists_valid = false;
+    sph_invalidate_lists(c);
     if (c->n_dyn_host <= 0) return 0;
     DevView d = sph_view(c);
     const int n = c->n_dyn_host, nb = (n + TPB - 1) / TPB;
@@ -644,7 +654,7 @@ int sphk_extract(SphContext* c, int field, void* dst) {
 }
 
 int sphk_insert(SphContext* c, int field, const void* src) {
-    if (field == SPH_F_X || field == SPH_F_MATERIAL || field == SPH_F_IS_DYNAMIC) c->lists_valid = false;
+    if (field == SPH_F_X || field == SPH_F_MATERIAL || field == SPH_F_IS_DYNAMIC) sph_invalidate_lists(c);
     if (c->N <= 0) return 0;
     DevView d = sph_view(c);
     hipLaunchKernelGGL(k_insert, dim3((c->N + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, field, c->x0_cold,
@@ -687,7 +697,7 @@ int sphk_rigid_partial16(SphContext* c, int object_id, int first, int count, dou
 }
 
 int sphk_rigid_apply16(SphContext* c, int object_id, const double* sums, int mode) {
-    c->lists_valid = false;
+    sph_invalidate_lists(c);
     DevView d = sph_view(c);
     const int n = c->n_dyn_host;
     const int nb = (mode == 1 && n > 0) ? (n + TPB - 1) / TPB : 1;
@@ -720,7 +730,7 @@ int sphk_df_advect(SphContext* c, bool fused_fluid_walls) {
     if (fused_fluid_walls) hipLaunchKernelGGL(k_df_advect<true>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c));
     else hipLaunchKernelGGL(k_df_advect<false>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c));
     SPH_LAUNCH_CHECK(c);
-    c->lists_valid = false;
+    sph_invalidate_lists(c);
     return 0;
 }
 
@@ -736,11 +746,16 @@ int sphk_df_density_error(SphContext* c, float offset, float* out_host) {
     double h = 0.0;
     if (c->N > 0) {
         DevView d = sph_view(c);
-        SPH_HIP(c, hipMemsetAsync(c->df_err, 0, sizeof(double), c->stream));
-        hipLaunchKernelGGL(k_df_density_error, dim3((c->N + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, offset, c->df_err);
+        int nb = (c->N + TPB - 1) / TPB;
+        if (nb > SPH_DF_ERR_BLOCKS) nb = SPH_DF_ERR_BLOCKS;
+        hipLaunchKernelGGL(k_df_density_error, dim3(nb), dim3(TPB), 0, c->stream, d, offset, c->df_part);
         SPH_LAUNCH_CHECK(c);
-        SPH_HIP(c, hipMemcpyAsync(&h, c->df_err, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        double* dev_out = nullptr;
+        SPH_HIP(c, hipHostGetDevicePointer((void**)&dev_out, c->h_df_err, 0));
+        hipLaunchKernelGGL(k_df_density_error_total, dim3(1), dim3(64), 0, c->stream, c->df_part, nb, dev_out);
+        SPH_LAUNCH_CHECK(c);
         SPH_HIP(c, hipStreamSynchronize(c->stream));
+        h = *(volatile double*)c->h_df_err;
     }
     *out_host = (float)h;
     return 0;

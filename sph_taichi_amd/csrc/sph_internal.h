@@ -24,6 +24,7 @@
 #define SPH_MATERIAL_FLUID 1  // particle_system.py:31
 #define SPH_MAX_TIMED_STEPS 128
 #define SPH_GLIST_ROWS 64
+#define SPH_DF_ERR_BLOCKS 512
 
 struct DevView {
     int N, G;
@@ -96,6 +97,10 @@ struct SphContext {
     size_t stage_bytes;
     bool have_keys, have_prefix, sorted;
     bool lists_valid;   // glist/gcnt describe the CURRENT positions and order (written by a list-writing brick sweep)
+    bool bricks_valid;  // brick_list/brick_count describe the current order for the target ranges in bricks_key
+    int bricks_key[5];  // brick shape id, tgt_lo, tgt_hi, tgt_lo2, tgt_hi2
+    double* h_df_err;   // pinned, device-visible: result of compute_density_error
+    double* df_part;    // [SPH_DF_ERR_BLOCKS] per-workgroup partial sums
     SphDfsphParams df;  // DFSPH solver knobs
     SphDfsphStats df_stats;
     double* df_err;     // device accumulator of compute_density_error
@@ -109,6 +114,8 @@ struct SphContext {
 };
 
 DevView sph_view(const SphContext* c);
+// particle positions / order / flags changed: neighbour lists and the non-empty-brick list are stale
+static inline void sph_invalidate_lists(SphContext* c) { c->lists_valid = false; c->bricks_valid = false; }
 int sph_fail(SphContext* c, int code, const char* what);
 
 #define SPH_HIP(ctx, expr)                                                        \

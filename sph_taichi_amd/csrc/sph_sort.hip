@@ -211,7 +211,7 @@ int sphk_sort_scatter(SphContext* c, bool sort_acc) {
                            c->vf[o], c->aux[o], c->key[o], c->acc_tmp, c->dyn_list, c->dyn_count);
     SPH_LAUNCH_CHECK(c);
     c->cur = o;
-    c->lists_valid = false;
+    sph_invalidate_lists(c);
     if (sort_acc) {
         float4* t = c->acc;
         c->acc = c->acc_tmp;

@@ -229,6 +229,33 @@ class ParticleSystem:
         mask = (self.object_id.to_numpy() == obj_id).nonzero()
         return {"position": self.x.to_numpy()[mask], "velocity": self.v.to_numpy()[mask]}
 
+    # ---- state checkpoint (the reference has none) ----------------------
+    _STATE_FIELDS = ("object_id", "x", "x_0", "v", "acceleration", "m_V", "m", "density", "pressure", "material",
+                     "color", "is_dynamic", "pid")
+
+    def save_state(self, path: str, **meta):
+        """Every per-particle array in the current (cell-sorted) order + rigid_rest_cm, as one .npz.  Restoring it
+        into a ParticleSystem built from the same scene continues the run exactly where it stopped."""
+        data = {f: getattr(self, f).to_numpy() for f in self._STATE_FIELDS}
+        if self.num_rigid_bodies > 0:
+            data["rigid_rest_cm"] = self.rigid_rest_cm.to_numpy()
+        data["particle_max_num"] = np.int64(self.particle_max_num)
+        for k, v in meta.items():
+            data["meta_" + k] = np.asarray(v)
+        np.savez_compressed(path, **data)
+
+    def load_state(self, path: str):
+        z = np.load(path)
+        if int(z["particle_max_num"]) != self.particle_max_num:
+            raise ValueError(f"checkpoint holds {int(z['particle_max_num'])} particles, this scene {self.particle_max_num}")
+        self.pid.from_numpy(z["pid"])                  # first: x_0 / color are keyed by the persistent id
+        for f in self._STATE_FIELDS:
+            if f != "pid":
+                getattr(self, f).from_numpy(z[f])
+        if "rigid_rest_cm" in z.files and self.num_rigid_bodies > 0:
+            self.rigid_rest_cm.from_numpy(z["rigid_rest_cm"])
+        return {k[5:]: z[k] for k in z.files if k.startswith("meta_")}
+
     def copy_to_vis_buffer(self, invisible_objects=[]):
         """particle_system.py:392-407 (host copy; there is no GGUI here)."""
         assert self.GGUI

@@ -38,6 +38,8 @@ def main(argv=None):
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--timing", action="store_true")
     ap.add_argument("--dump_npz", default="", help="write the final per-particle state here")
+    ap.add_argument("--save_state", default="", help="write a restartable checkpoint (.npz) after the last frame")
+    ap.add_argument("--load_state", default="", help="continue from a checkpoint written by --save_state")
     args = ap.parse_args(argv)
 
     scene_path = args.scene_file
@@ -55,6 +57,9 @@ def main(argv=None):
     ps = ParticleSystem(config, GGUI=False, device=args.device, scene_dir=scene_dir, verbose=True)
     solver = ps.build_solver()
     solver.initialize()
+    if args.load_state:
+        meta = ps.load_state(args.load_state)
+        print(f"restored {args.load_state} (frames done: {int(meta.get('frames', 0))})")
     if args.timing:
         ps.set_option(_lib.OPT_TIMING, 1)
 
@@ -85,6 +90,8 @@ def main(argv=None):
         report["breakdown_ms"] = {"sort": tm.sort_ms / k, "neighbour": tm.neighbour_ms / k, "force": tm.force_ms / k,
                                   "integrate": tm.integrate_ms / k}
     print(json.dumps(report))
+    if args.save_state:
+        ps.save_state(args.save_state, frames=args.frames, scene=scene_name)
     if args.dump_npz:
         np.savez_compressed(args.dump_npz, **{f: getattr(ps, f).to_numpy() for f in
                                               ("object_id", "x", "v", "density", "pressure", "m_V", "pid")})

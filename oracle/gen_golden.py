@@ -49,6 +49,7 @@ def run_reference(scene_dict, n_steps, per_kernel_first_step=True):
     import taichi as ti                      # the shim
     from config_builder import SimConfig     # the reference's
     from particle_system import ParticleSystem
+    os.chdir(ROOT)      # geometryFile paths in the fixtures are relative to the repo root
     with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as fh:
         json.dump(scene_dict, fh)
         path = fh.name
@@ -126,6 +127,20 @@ def main():
         "ref_fluid_rigid": (scenes.fluid_with_rigid_blocks(fluid_counts=(8, 8, 6), static_counts=(12, 2, 10),
                                                            dyn_counts=(4, 4, 4)), 8),
     }
+    # shape-matched RigidBodies (sph_base.py:87-89, 182-260) through the reference's own load_rigid_body; the mesh
+    # is a cube OBJ written next to the fixture (the trimesh stand-in voxelises it, see taichi_shim/trimesh)
+    obj = os.path.join(ROOT, "tests", "golden", "cube_0p1.obj")
+    scenes.write_cube_obj(obj, (0.0, 0.0, 0.0), 0.1)
+    # (the voxel points sit on the pitch lattice, i.e. half of them exactly on cell boundaries: the bodies get
+    # sideways velocity so that later hashes are not decided by the last bit of the shape-matching sums)
+    d3 = scenes.fluid_with_rigid_bodies("tests/golden/cube_0p1.obj",
+                                        body_velocities=((0.3, -2.0, 0.2), (-0.25, -2.0, 0.35)))
+    d3["FluidBlocks"][0]["end"] = scenes.lattice_end((0.1, 0.1, 0.1), (10, 8, 8))
+    jobs["ref_rigid_bodies"] = (d3, 8)
+    d4 = copy.deepcopy(d3)
+    d4["Configuration"]["simulationMethod"] = 4
+    d4["Configuration"]["timeStepSize"] = 0.002
+    jobs["ref_dfsph_rigid_bodies"] = (d4, 6)
     # DFSPH (simulationMethod 4, DFSPH.py): fluid hitting a wall corner; fluid on a static slab with a dynamic block
     d1 = scenes.fluid_only(counts=(8, 9, 6), start=(0.05, 0.05, 0.05), velocity=(-4.0, -6.0, -3.0),
                            domain_end=(0.6, 0.6, 0.5))      # both solvers iterate (up to 3 / 2 extra iterations)

@@ -501,7 +501,8 @@ def run_slab_bench(args, rank, world, local_rank):
                    "particles_owned_sum": int(own.item()), "cuts": s.cuts, "halo_layers": s.halo,
                    "sent_records_per_step": round(s.stats["sent"] / max(args.steps + args.warmup + 1, 1), 1),
                    "backend": dist.get_backend(),
-                   "parallelism": f"x-slab x{world}, 1 exchange/step over RCCL P2P"},
+                   "parallelism": f"x-slab x{world}, 1 exchange/step over "
+                                  f"{'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} P2P"},
         "steps_per_s_job": round(steps_per_s, 3),
         "roofline": None, "cpu_baseline": None,
     }

@@ -66,16 +66,17 @@ def write_cube_obj(path, lo, side):
             fh.write(f"f {a} {b} {c}\nf {a} {c} {d}\n")
 
 
-def fluid_with_rigid_bodies(obj_path, fluid_velocity=(0.0, -1.0, 0.0)):
+def fluid_with_rigid_bodies(obj_path, fluid_velocity=(0.0, -1.0, 0.0), body_velocities=((0.0, -2.0, 0.0), (0.0, -2.0, 0.0))):
     """Two dynamic RigidBodies (voxelised 0.1 cubes, one rotated by 30 deg) dropping into a fluid block next to a
     static body: shape matching (sph_base.py:182-260) + two-way coupling."""
     write_cube_obj(obj_path, (0.0, 0.0, 0.0), 0.1)
     sd = fluid_only(counts=(14, 8, 12), start=(0.1, 0.1, 0.1), velocity=fluid_velocity)
-    body = lambda oid, tr, ang, dyn, rho: {"objectId": oid, "geometryFile": obj_path, "translation": list(tr),
-                                           "rotationAxis": [0, 0, 1], "rotationAngle": ang, "scale": [1, 1, 1],
-                                           "velocity": [0.0, -2.0, 0.0], "density": rho, "color": [255, 255, 255],
-                                           "isDynamic": dyn}
-    sd["RigidBodies"] = [body(1, (0.14, 0.26, 0.14), 0, True, 600.0), body(2, (0.28, 0.27, 0.18), 30, True, 2500.0),
+    body = lambda oid, tr, ang, dyn, rho, vel=(0.0, 0.0, 0.0): {
+        "objectId": oid, "geometryFile": obj_path, "translation": list(tr), "rotationAxis": [0, 0, 1],
+        "rotationAngle": ang, "scale": [1, 1, 1], "velocity": list(vel), "density": rho, "color": [255, 255, 255],
+        "isDynamic": dyn}
+    sd["RigidBodies"] = [body(1, (0.14, 0.26, 0.14), 0, True, 600.0, body_velocities[0]),
+                         body(2, (0.28, 0.27, 0.18), 30, True, 2500.0, body_velocities[1]),
                          body(3, (0.50, 0.10, 0.14), 0, False, 1000.0)]
     return sd
 

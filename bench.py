@@ -122,7 +122,7 @@ def main():
     ap.add_argument("--gather-impl", type=int, default=1)
     ap.add_argument("--brick-shape", type=int, default=0)
     ap.add_argument("--fused", type=int, default=1)
-    ap.add_argument("--cpu-steps", type=int, default=3, help="CPU-oracle sample size (0 = skip the baseline leg)")
+    ap.add_argument("--cpu-steps", type=int, default=10, help="CPU-oracle sample size (0 = skip the baseline leg)")
     ap.add_argument("--sweep", action="store_true", help="also time every gather variant (stderr table)")
     ap.add_argument("--ablate", action="store_true", help="profiling: time the sweeps with sections skipped (stderr)")
     ap.add_argument("--ablate-mask", type=int, default=0, help="profiling: run the whole bench with this ablation mask (results invalid)")

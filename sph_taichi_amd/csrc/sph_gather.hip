@@ -10,11 +10,15 @@
 //    the flatten order is z-fastest (particle_system.py:294).  Candidates come
 //    through L1/L2.  Same traversal order as the reference.  Used for small
 //    target sets (rigid particles) and as the overflow path.
-//  * k_gather_brick  : a 256-lane workgroup owns a BXxBYxBZ brick of cells,
+//  * k_gather_brick  : a 256-lane workgroup owns a BXxBYxBZ brick of cells and
 //    stages the brick + one-cell shell (per column one contiguous segment) in
-//    LDS, then every lane (a) filters its candidates into a private LDS index
-//    list (cheap loop: ds_read_b128 + 7 VALU), (b) runs the expensive pair
-//    physics over the list only, so lanes stay converged in the costly part.
+//    LDS.  FILTERING sweeps (density) test every candidate with the expanded
+//    square (ds_read_b128 + 3 FMA + compare), collect hits in bitmask registers
+//    and write them out as u16 neighbour lists in HBM; LIST-READING sweeps (the
+//    fused force sweep, every DFSPH sweep after the density one) skip the filter
+//    and run their pair physics over those lists, gathering the neighbour's
+//    other records through L2 with the next entry prefetched.
+// The DFSPH pair terms (DFSPH.py) are further MODEs of the same two kernels.
 //
 // No MFMA: this is a bandwidth/VALU-bound gather, not a contraction.
 #include "sph_internal.h"
@@ -450,10 +454,9 @@ __global__ __launch_bounds__(TPB) void k_gather_bvol_split(DevView d, const int*
 // ---------------------------------------------------------------------------
 // v1: LDS-staged cell bricks
 // ---------------------------------------------------------------------------
-// LDS holds the shell's records as two float2 arrays, (x,y) and (z,m_V): with 8
-// particles per cell the slots of lanes in different cells differ by multiples
-// of 8, which is a 2-way bank conflict for ds_read_b128's interleaved lane
-// groups but conflict-free for ds_read_b64.
+// LDS holds one float4 per shell record (see the carve in BrickCfg): for a
+// filtering sweep (-2x', -2y', -2z', |x'|^2) in shell-local coordinates plus a
+// separate m_V array, for a list-reading sweep the record (x, y, z, m_V) itself.
 // List entries are u16: (shell column << 11) | LDS slot, so CAP <= 2048 and
 // NCOL <= 32; the global index of a slot is sColG[col] + slot - sColS[col].
 // In the fused step the density sweep writes each target's list to HBM

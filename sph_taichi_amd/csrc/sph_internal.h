@@ -6,6 +6,8 @@
 //   vf [cap] float4 = (vx, vy, vz, bits(flags))       hot, ping-pong
 //   aux[cap] float4 = (m, density, pressure, bits(pid)) hot, ping-pong
 //   eos[cap] float4 = (p/rho^2, m/rho_raw, m, rho)    written by density+EOS, read by force
+//                     (DFSPH: (dfsph_factor, density_adv, m, rho))
+//   glist[64*cap] u16, gcnt[cap] u8                   neighbour lists: row k of particle i at glist[k*cap + i]
 //   acc[cap] float4 = (ax, ay, az, 0)
 //   key[cap] int    = grid_ids                        ping-pong
 //   x0_cold [3*cap] f32, color_cold [3*cap] i32       indexed by pid, never moved

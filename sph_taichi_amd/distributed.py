@@ -214,6 +214,7 @@ class SlabSolver:
         self.transport = None
         self.has_left, self.has_right = rank > 0, rank < world - 1
         self.stats = {"sent": 0, "received": 0}
+        self.host_ms = {"forces_pack": 0.0, "exchange": 0.0, "advance": 0.0, "steps": 0}
         # shape-matched bodies (sph_base.py:247-260 iterates object_id_rigid_body; only dynamic ones move)
         sc = self.ps._scene
         self.dynamic_bodies = sorted(sc.dynamic_rigid_ids)
@@ -353,15 +354,27 @@ class SlabSolver:
                                        self._alloc_recv)
 
     def step(self, n=1):
+        """`self.host_ms` accumulates where the HOST spends a step: enqueueing + waiting for the packers
+        ("forces_pack"), inside the exchange ("exchange"), and enqueueing the sort + waiting for its layer offsets
+        ("advance").  The GPU keeps working through all three (interior force sweep / density sweep), so these are
+        not additive GPU costs; they show whether the exchange stays inside its hiding window."""
+        import time
+        hm = self.host_ms
         for _ in range(n):
+            t0 = time.perf_counter()
             if self.dynamic_bodies:
                 self.phase_forces(pack=False)
                 self.solve_rigid_bodies()
                 sent = self.pack_now()
             else:
                 sent = self.phase_forces()
+            t1 = time.perf_counter()
             rL, mL, rR, mR = self._exchange(*sent)
+            t2 = time.perf_counter()
             self.phase_advance(rL, mL, rR, mR)
+            t3 = time.perf_counter()
+            hm["forces_pack"] += (t1 - t0) * 1e3; hm["exchange"] += (t2 - t1) * 1e3; hm["advance"] += (t3 - t2) * 1e3
+            hm["steps"] += 1
 
     def initialize(self):
         """SPHBase.initialize() (sph_base.py:80-85) for a slab: neighbour structure with halos, then the
@@ -479,6 +492,7 @@ def run_slab_bench(args, rank, world, local_rank):
     s.ps.sync()
     torch.cuda.synchronize()
     dist.barrier()
+    s.host_ms = {k: 0 if k == "steps" else 0.0 for k in s.host_ms}
     t0 = time.perf_counter()
     s.step(args.steps)
     s.ps.sync()
@@ -501,6 +515,8 @@ def run_slab_bench(args, rank, world, local_rank):
                    "particles_owned_sum": int(own.item()), "cuts": s.cuts, "halo_layers": s.halo,
                    "sent_records_per_step": round(s.stats["sent"] / max(args.steps + args.warmup + 1, 1), 1),
                    "backend": dist.get_backend(),
+                   "rank0_host_ms_per_step": {k: round(v / max(s.host_ms["steps"], 1), 4)
+                                              for k, v in s.host_ms.items() if k != "steps"},
                    "parallelism": f"x-slab x{world}, 1 exchange/step over "
                                   f"{'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} P2P"},
         "steps_per_s_job": round(steps_per_s, 3),

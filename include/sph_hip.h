@@ -1,5 +1,6 @@
 /*
- * sph_hip.h -- C ABI of libsph_hip.so: the MI355X (gfx950) WCSPH step.
+ * sph_hip.h -- C ABI of libsph_hip.so: the MI355X (gfx950) WCSPH step (and, at the end of the file,
+ * the DFSPH step on the same neighbour machinery).
  *
  * The reference (erizmr/SPH_Taichi) has no FFI layer: its device code is
  * Taichi @ti.kernel Python.  This header is the boundary a maintainer binds
@@ -9,10 +10,11 @@
  *
  * Contract
  *  - One opaque context per GPU.  The context owns every device buffer and
- *    (unless sph_set_stream is used) one HIP stream.  A context is driven by
+ *    (unless a stream is handed to sph_create) one HIP stream.  A context is driven by
  *    one host thread at a time.
  *  - Compute entry points ENQUEUE on the context's stream and return;
- *    sph_download / sph_sync / sph_get_timings / sph_get_counts synchronise.
+ *    sph_download / sph_sync / sph_get_timings / sph_layer_offsets synchronise (and the DFSPH solver loops,
+ *    once per iteration, like the reference's compute_density_error).
  *  - Every function returns 0 on success, a negative SPH_E_* code or a positive
  *    hipError_t otherwise; sph_last_error(ctx) gives the message.  Nothing
  *    throws.
@@ -33,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SPH_ABI_VERSION 1
+#define SPH_ABI_VERSION 2
 
 typedef struct SphContext SphContext;
 

@@ -52,7 +52,7 @@ F_OBJECT_ID, F_X, F_X_0, F_V, F_ACCELERATION, F_M_V, F_M, F_DENSITY, F_PRESSURE,
 OPT_GATHER_IMPL, OPT_TIMING, OPT_FUSED_STEP, OPT_BRICK_SHAPE, OPT_NO_DYNAMIC_SOLIDS, OPT_DEBUG_ABLATE, \
     OPT_SLAB_DROP_OUTSIDE = range(7)
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/sph_hip.h declares: (name, restype, argtypes)
 _ctx = C.c_void_p

@@ -79,7 +79,7 @@ def test_library_exports_every_header_symbol():
     lib = _lib.load()                                             # builds with hipcc if needed; dlopen
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.sph_abi_version() == 1
+    assert lib.sph_abi_version() == _lib.ABI_VERSION
     assert ctypes.sizeof(_lib.SphParams) == 4 * (2 + 3 + 3 + 2 + 10 + 3 + 3 + 1 + 3 + 4)
 
 

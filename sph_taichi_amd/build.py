@@ -1,6 +1,8 @@
 """Build libsph_hip.so (hipcc, gfx950 only) in-tree next to this file."""
 from __future__ import annotations
 
+import fcntl
+import hashlib
 import os
 import shutil
 import subprocess
@@ -22,20 +24,48 @@ def hipcc() -> str:
     return exe
 
 
+STAMP = LIB + ".stamp"
+
+
+def _fingerprint() -> str:
+    """Hash of every source, header and flag: staleness must not depend on file times (a snapshot copied to
+    another box keeps contents, not necessarily mtimes)."""
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for path in [os.path.join(CSRC, s) for s in SOURCES] + HEADERS:
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def stale() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    try:
+        return open(STAMP).read().strip() != _fingerprint()
+    except OSError:
+        return True
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    if force or stale():
-        cmd = [hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True, cwd=CSRC)
+    """Several ranks may get here at once (torch.distributed.run starts one process per GPU): one of them builds,
+    under a file lock, into a temporary file that is renamed into place; the others wait and find it fresh."""
+    if not (force or stale()):
+        return LIB
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or stale():
+                tmp = f"{LIB}.tmp.{os.getpid()}"
+                cmd = [hipcc()] + FLAGS + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.run(cmd, check=True, cwd=CSRC)
+                os.replace(tmp, LIB)
+                with open(STAMP + ".tmp", "w") as fh:
+                    fh.write(_fingerprint() + "\n")
+                os.replace(STAMP + ".tmp", STAMP)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 

@@ -251,12 +251,13 @@ def main():
     dominant = max(kernels, key=lambda k_: kernels[k_][1])
     alg_bytes, dom_ms = kernels[dominant]
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    traffic = None
+    traffic = valu_busy = None
     try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (same workload / variant only)
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         if pm["workload"] == args.workload and args.gather_impl == 1 and args.brick_shape == 0 and args.fused == 1:
             kk = pm["kernels"][dominant]
             traffic = kk["fetch_kb"] * 1024 * 2 + kk["write_kb"] * 1024
+            valu_busy = kk.get("valu_busy_frac")
     except Exception:
         traffic = None
     line = {
@@ -274,7 +275,9 @@ def main():
         "roofline": {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4),
-                     "note": "gather sweeps are VALU/LDS-bound, not HBM-bound (DESIGN.md section 4); "
+                     "valu_busy_frac": valu_busy,
+                     "note": "gather sweeps are VALU-issue-bound, not HBM-bound (DESIGN.md section 4; valu_busy_frac = share "
+                             "of SIMD cycles issuing vector ALU instructions, from the committed PMC pass); "
                              "traffic = rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch (profiles/pmc_traffic.json)"},
         "roofline_kernels": {k_: {"alg_bytes": v[0], "avg_launch_ms": round(v[1], 4),
                                   "achieved_GBs": round(v[0] / (v[1] * 1e-3) / 1e9, 2) if v[1] > 0 else 0.0}

@@ -690,7 +690,10 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
                     const unsigned tag = (unsigned)ncol << 11;
 // Hits are collected in a per-run bitmask register (no LDS traffic while filtering) and turned into list
 // entries once per chunk of <= 32 candidates: ~7 ds_write per run instead of one per candidate.
-#define SPH_TEST(Q_) (fmaf(txl_, (Q_).x, fmaf(tyl_, (Q_).y, fmaf(tzl_, (Q_).z, (Q_).w))) < thr)
+// One candidate = 3 FMA + 1 add + 1 v_alignbit: the test value r2' - thr' is negative for a hit, and alignbit shifts
+// its SIGN BIT into the mask ((mask << 1) | sign) -- no compare, no select.  After n candidates, candidate k sits at
+// bit n-1-k; hits are emitted from the top bit down, i.e. in ascending candidate order.
+#define SPH_ACC(Q_) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(fmaf(txl_, (Q_).x, fmaf(tyl_, (Q_).y, fmaf(tzl_, (Q_).z, (Q_).w - thr)))), 31)
                     for (int base = lo; base < hi; base += 32) {
                         const int n = min(32, hi - base);
                         unsigned mask = 0;
@@ -699,20 +702,18 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
                             const float4* q = &sQ[base + k];
                             const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
                             const float4 q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7];
-                            const unsigned byte = (SPH_TEST(q0) ? 1u : 0u) | (SPH_TEST(q1) ? 2u : 0u) |
-                                                  (SPH_TEST(q2) ? 4u : 0u) | (SPH_TEST(q3) ? 8u : 0u) |
-                                                  (SPH_TEST(q4) ? 16u : 0u) | (SPH_TEST(q5) ? 32u : 0u) |
-                                                  (SPH_TEST(q6) ? 64u : 0u) | (SPH_TEST(q7) ? 128u : 0u);
-                            mask |= byte << k;
+                            SPH_ACC(q0); SPH_ACC(q1); SPH_ACC(q2); SPH_ACC(q3);
+                            SPH_ACC(q4); SPH_ACC(q5); SPH_ACC(q6); SPH_ACC(q7);
                         }
                         for (; k < n; ++k) {
                             const float4 q0 = sQ[base + k];
-                            mask |= (SPH_TEST(q0) ? 1u : 0u) << k;
+                            SPH_ACC(q0);
                         }
                         const unsigned tagbase = tag | (unsigned)base;
                         while (mask) {  // rows coalesce across the wave's lanes (consecutive gi)
-                            const unsigned bit = (unsigned)__ffs((int)mask) - 1u;
-                            mask &= mask - 1u;
+                            const unsigned top = 31u - (unsigned)__clz((int)mask);
+                            mask &= ~(1u << top);
+                            const unsigned bit = (unsigned)(n - 1) - top;
                             if (cnt < CFG::LISTCAP) gl[(size_t)cnt * cap] = (unsigned short)(tagbase + bit);
                             ++cnt;
                             if (mode_inline_physics<MODE>()) {
@@ -732,7 +733,7 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
                             }
                         }
                     }
-#undef SPH_TEST
+#undef SPH_ACC
                 }
             }
             // list overflow (extreme compression): the list-reading sweep must take the exact slow path; this

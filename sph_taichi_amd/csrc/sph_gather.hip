@@ -130,7 +130,9 @@ __device__ __forceinline__ void target_init(const DevView& d, Target& t, const f
 // r.norm(), r / (r_norm * h), x / y become r2 * rsq(r2), r * (rsq * 1/h), x * rcp(y):
 // same formulas, a few ulp apart, far inside the 1e-4 position budget; hipcc's
 // correctly-rounded div/sqrt expansions (~10 VALU each) were the dominant cost.
-__device__ __forceinline__ float sph_rsq(float x) { return x > 0.0f ? __builtin_amdgcn_rsqf(x) : 0.0f; }
+// (x = 0 only for a particle paired with itself or an exact duplicate: rsq(1e-30) * 0 = 0 gives r = 0 like the
+// guarded form did, with one v_max instead of a compare + select)
+__device__ __forceinline__ float sph_rsq(float x) { return __builtin_amdgcn_rsqf(fmaxf(x, 1e-30f)); }
 __device__ __forceinline__ float sph_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
 // sph_base.py:23-44 cubic_kernel as a function of q = r/h (q <= 1 is guaranteed by the caller's r < h)
@@ -691,29 +693,30 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
 // Hits are collected in a per-run bitmask register (no LDS traffic while filtering) and turned into list
 // entries once per chunk of <= 32 candidates: ~7 ds_write per run instead of one per candidate.
 // One candidate = 3 FMA + 1 add + 1 v_alignbit: the test value r2' - thr' is negative for a hit, and alignbit shifts
-// its SIGN BIT into the mask ((mask << 1) | sign) -- no compare, no select.  After n candidates, candidate k sits at
-// bit n-1-k; hits are emitted from the top bit down, i.e. in ascending candidate order.
+// its SIGN BIT into the mask ((mask << 1) | sign) -- no compare, no select.  A chunk is walked from its last candidate
+// to its first, so candidate k ends up at bit k and the hits come out in ascending order with ffs / clear-lowest-bit.
 #define SPH_ACC(Q_) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(fmaf(txl_, (Q_).x, fmaf(tyl_, (Q_).y, fmaf(tzl_, (Q_).z, (Q_).w - thr)))), 31)
                     for (int base = lo; base < hi; base += 32) {
                         const int n = min(32, hi - base);
                         unsigned mask = 0;
-                        int k = 0;
-                        for (; k + 8 <= n; k += 8) {
-                            const float4* q = &sQ[base + k];
-                            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-                            const float4 q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7];
-                            SPH_ACC(q0); SPH_ACC(q1); SPH_ACC(q2); SPH_ACC(q3);
-                            SPH_ACC(q4); SPH_ACC(q5); SPH_ACC(q6); SPH_ACC(q7);
-                        }
-                        for (; k < n; ++k) {
+                        int k = n;
+                        while (k & 7) {  // the ragged end first
+                            --k;
                             const float4 q0 = sQ[base + k];
                             SPH_ACC(q0);
                         }
+                        while (k > 0) {
+                            k -= 8;
+                            const float4* q = &sQ[base + k];
+                            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                            const float4 q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7];
+                            SPH_ACC(q7); SPH_ACC(q6); SPH_ACC(q5); SPH_ACC(q4);
+                            SPH_ACC(q3); SPH_ACC(q2); SPH_ACC(q1); SPH_ACC(q0);
+                        }
                         const unsigned tagbase = tag | (unsigned)base;
                         while (mask) {  // rows coalesce across the wave's lanes (consecutive gi)
-                            const unsigned top = 31u - (unsigned)__clz((int)mask);
-                            mask &= ~(1u << top);
-                            const unsigned bit = (unsigned)(n - 1) - top;
+                            const unsigned bit = (unsigned)__ffs((int)mask) - 1u;
+                            mask &= mask - 1u;
                             if (cnt < CFG::LISTCAP) gl[(size_t)cnt * cap] = (unsigned short)(tagbase + bit);
                             ++cnt;
                             if (mode_inline_physics<MODE>()) {
@@ -729,7 +732,10 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
                                 const float tq = fmaxf(1.0f - qn, 0.0f);
                                 const float inner = d.k_w * ((6.0f * qn - 6.0f) * qn * qn + 1.0f);
                                 const float outer = d.k_w * 2.0f * (tq * tq * tq);
-                                t.s0 += sW[j] * (qn <= 0.5f ? inner : outer);
+                                // (m_V through an explicit 32-bit LDS byte offset: derived from &sQ[j] the compiler
+                                // emits a 64-bit multiply-add for this address)
+                                const float mVj = *reinterpret_cast<const float*>(smem + CFG::off_w(true) + (j << 2));
+                                t.s0 += mVj * (qn <= 0.5f ? inner : outer);
                             }
                         }
                     }

@@ -460,7 +460,7 @@ __global__ __launch_bounds__(TPB) void k_gather_bvol_split(DevView d, const int*
 // filtering sweep (-2x', -2y', -2z', |x'|^2) in shell-local coordinates plus a
 // separate m_V array, for a list-reading sweep the record (x, y, z, m_V) itself.
 // List entries are u16: (shell column << 11) | LDS slot, so CAP <= 2048 and
-// NCOL <= 32; the global index of a slot is sColG[col] + slot - sColS[col].
+// NCOL <= 32; the global index of a slot is slot + sColG[col] (sColG = global start - LDS start of the column).
 // In the fused step the density sweep writes each target's list to HBM
 // (glist[k*cap + i], gcnt[i]) and the force sweep -- same positions, same
 // brick layout -- reads it back instead of filtering again.
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
     // coordinates are <= 6 cells, so the cancellation error (~1e-8) is far below the 2e-4 h^2 filter margin,
     // and x' = x - O is exact (Sterbenz) away from the first cells, so phase 2 recovers x_i - x_j unchanged.
     int* sCE = reinterpret_cast<int*>(smem + CFG::off_ce(HAS_W));      // [NCOL][NZS] raw cell_end values of the shell
-    int* sColG = reinterpret_cast<int*>(smem + CFG::off_colg(HAS_W));  // global start of the column segment
+    int* sColG = reinterpret_cast<int*>(smem + CFG::off_colg(HAS_W));  // global - LDS start of the column segment
     int* sColS = reinterpret_cast<int*>(smem + CFG::off_cols(HAS_W));  // LDS start of the column segment (+ total at [64])
     int* sTG = reinterpret_cast<int*>(smem + CFG::off_tg(HAS_W));      // global start of the column's targets
     int* sTOff = reinterpret_cast<int*>(smem + CFG::off_toff(HAS_W));  // target-number start of the column (+ total at [64])
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
         }
         const int incl = sph_wave_inclusive_scan(len, lane);
         const int tincl = sph_wave_inclusive_scan(tlen, lane);
-        sColG[lane] = gstart;
+        sColG[lane] = gstart - (incl - len);  // global index = LDS slot + this
         sColS[lane] = incl - len;
         sTG[lane] = tstart;
         sTOff[lane] = tincl - tlen;
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
 #pragma unroll
             for (int step = 16; step > 0; step >>= 1)
                 if (sColS[col + step] <= idx) col += step;
-            buf[u] = d.xm[sColG[col] + (idx - sColS[col])];
+            buf[u] = d.xm[sColG[col] + idx];
         }
 #pragma unroll
         for (int u = 0; u < CFG::PER; ++u) {
@@ -668,7 +668,7 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
         const bool g = target_gathers<MODE>(t.flags);
         bool walk = g && overflow;
         int cnt = 0;
-        const int li = sColS[col] + (gi - sColG[col]);  // own LDS slot
+        const int li = gi - sColG[col];  // own LDS slot
         if (g && !overflow && !mode_reads_list<MODE>() && !(d.ablate & 4)) {
             const int ix = sx0 + col / ncy, iy = sy0 + col % ncy;
             const int cz = key_i - sph_flatten(d, ix, iy, 0);  // key = flatten(ix, iy, cz)
@@ -686,7 +686,7 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
                     const int ny = iy + dy;
                     if (ny < 0 || ny >= d.ny) continue;
                     const int ncol = (nx - sx0) * ncy + (ny - sy0);
-                    const int rel = sColS[ncol] - sColG[ncol];
+                    const int rel = -sColG[ncol];
                     const int lo = sCE[ncol * CFG::NZS + klo] + rel;
                     const int hi = sCE[ncol * CFG::NZS + khi + 1] + rel;
                     const unsigned tag = (unsigned)ncol << 11;
@@ -758,47 +758,50 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
         }
         if (mode_writes_list<MODE>() && g && overflow) gcnt[gi] = (unsigned char)SPH_CNT_WALK;
         if (g && !walk && !(d.ablate & 1) && !mode_inline_physics<MODE>()) {
-            // phase 2: pair physics over the list; the next entry's records are prefetched
-            unsigned e1 = 0, e2 = 0;  // entries k+1 and k+2
-            if (cnt > 0) e1 = glist[gi];
-            if (cnt > 1) e2 = glist[(size_t)cap + gi];
-            float4 An = make_float4(0.f, 0.f, 0.f, 0.f);
-            float4 Bn = make_float4(0.f, 0.f, 0.f, 0.f), Cn = Bn;
-            int gn = 0, jn = -1;
-            if (cnt > 0) {
-                jn = e1 & 2047;
-                const int c2 = e1 >> 11;
-                An = sQ[jn];  // list-reading sweeps: (x, y, z, m_V)
-                if (HAS_W) An.w = sW[jn];
-                gn = sColG[c2] + (jn - sColS[c2]);
-                if (mode_needs_B<MODE>()) Bn = d.vf[gn];
-                if (mode_needs_C<MODE>()) Cn = load_C_global<MODE>(d, gn);
-            }
+            // phase 2: pair physics over the list.  Register sets rotate: while pair k is computed from one, the
+            // records of the next entries are in flight into the others.  Every fetch is UNCONDITIONAL (past the end it re-reads
+            // the last entry), so each set is always defined by loads and never by a copy of the other -- the
+            // conditional form cost ~30 v_mov per pair in register shuffling.
             const float txl = t.x - Ox, tyl = t.y - Oy, tzl = t.z - Oz;
             (void)txl; (void)tyl; (void)tzl;
-            for (int k = 0; k < cnt; ++k) {
-                const float4 A = An;
-                const float4 B = Bn, Cc = Cn;
-                const int gj = gn, j = jn;
-                if (k + 1 < cnt) {
-                    jn = e2 & 2047;
-                    const int c2 = e2 >> 11;
-                    An = sQ[jn];
-                    if (HAS_W) An.w = sW[jn];
-                    gn = sColG[c2] + (jn - sColS[c2]);
-                    if (mode_needs_B<MODE>()) Bn = d.vf[gn];
-                    if (mode_needs_C<MODE>()) Cn = load_C_global<MODE>(d, gn);
-                    if (k + 2 < cnt) e2 = glist[(size_t)(k + 2) * cap + gi];
-                }
+            struct Slot { float4 A, B, C; int g, j; };
+            auto fetch = [&](Slot& s_, unsigned e) {
+                s_.j = e & 2047;
+                s_.A = sQ[s_.j];  // list-reading sweeps: (x, y, z, m_V)
+                if (HAS_W) s_.A.w = sW[s_.j];
+                s_.g = sColG[e >> 11] + s_.j;
+                s_.B = mode_needs_B<MODE>() ? d.vf[s_.g] : make_float4(0.f, 0.f, 0.f, 0.f);
+                s_.C = mode_needs_C<MODE>() ? load_C_global<MODE>(d, s_.g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            };
+            auto pair = [&](const Slot& s_) {
                 // filtering sweeps hold x_j' = -A/2 in shell-local coordinates; list-reading sweeps hold x_j itself
-                const float rx = HAS_W ? fmaf(0.5f, A.x, txl) : t.x - A.x;
-                const float ry = HAS_W ? fmaf(0.5f, A.y, tyl) : t.y - A.y;
-                const float rz = HAS_W ? fmaf(0.5f, A.z, tzl) : t.z - A.z;
+                const float rx = HAS_W ? fmaf(0.5f, s_.A.x, txl) : t.x - s_.A.x;
+                const float ry = HAS_W ? fmaf(0.5f, s_.A.y, tyl) : t.y - s_.A.y;
+                const float rz = HAS_W ? fmaf(0.5f, s_.A.z, tzl) : t.z - s_.A.z;
                 const float r2 = rx * rx + ry * ry + rz * rz;
                 const float rinv = sph_rsq(r2);
                 const float rn = r2 * rinv;
-                if (sph_within<MODE>(d, r2, rn) && j != li)  // particle_system.py:385
-                    pair_physics<MODE>(d, t, rx, ry, rz, r2, rn, rinv, A, B, Cc, gj);
+                if (sph_within<MODE>(d, r2, rn) && s_.j != li)  // particle_system.py:385
+                    pair_physics<MODE>(d, t, rx, ry, rz, r2, rn, rinv, s_.A, s_.B, s_.C, s_.g);
+            };
+            if (cnt > 0) {
+                const unsigned short* gl = glist + gi;  // entry k of this target: gl[k * cap]
+                const int last = cnt - 1;
+                Slot s0, s1, s2;  // three sets: the records of entries k+1 and k+2 are in flight while pair k is computed
+                unsigned ea = gl[0], eb = gl[(size_t)min(1, last) * cap], ec = gl[(size_t)min(2, last) * cap];
+                fetch(s0, ea);
+                fetch(s1, eb);
+                for (int k = 0; k < cnt; k += 3) {
+                    fetch(s2, ec);
+                    ea = gl[(size_t)min(k + 3, last) * cap];
+                    pair(s0);
+                    fetch(s0, ea);
+                    eb = gl[(size_t)min(k + 4, last) * cap];
+                    if (k + 1 < cnt) pair(s1);
+                    fetch(s1, eb);
+                    ec = gl[(size_t)min(k + 5, last) * cap];
+                    if (k + 2 < cnt) pair(s2);
+                }
             }
         }
         if (walk) {

@@ -1,4 +1,4 @@
-"""Independent O(N^2) NumPy restatement of one WCSPH step (no grid, no sort).
+"""Independent O(N^2) NumPy restatement of one WCSPH step (no grid, no sort) and of the DFSPH neighbour sums.
 
 TEST INFRASTRUCTURE ONLY.  Cross-checks oracle/sph_oracle.c's neighbour search:
 the neighbour set here is { j != i : |x_i - x_j| < h } computed from a dense
@@ -151,6 +151,41 @@ class Brute:
         vn = v - f32(1.5) * vd[:, None] * vec
         a["x"] = np.where(sel[:, None], xn, x).astype(f32)
         a["v"] = np.where(hit[:, None], vn, v).astype(f32)
+
+    # ---- DFSPH (DFSPH.py:116-221): the three neighbour sums, no solver loops ----
+    def dfsph_factor(self):
+        """DFSPH.py:116-154: -1 / (sum_{fluid j} |m_V_j gradW_ij|^2 + |sum_j m_V_j gradW_ij|^2), 0 if the sum <= 1e-6."""
+        a = self.a
+        rvec, rn, nb = self._pairs()
+        g = a["m_V"][None, :, None] * _gradW(rvec, rn, self.h, self.kd)
+        g = np.where(nb[..., None], g, f32(0))
+        fluid = a["material"] == 1
+        sq = (g * g).sum(axis=2, dtype=f32)
+        s = np.where(fluid[None, :], sq, f32(0)).sum(axis=1, dtype=f32)
+        gi = g.sum(axis=1, dtype=f32)
+        s = s + (gi * gi).sum(axis=1, dtype=f32)
+        with np.errstate(divide="ignore"):
+            fac = np.where(s > f32(1e-6), f32(-1.0) / s, f32(0))
+        return np.where(fluid, fac, f32(0)).astype(f32)
+
+    def dfsph_velocity_divergence(self):
+        """sum_j m_V_j (v_i - v_j) . gradW_ij and the neighbour count (DFSPH.py:183-197, 212-221)."""
+        a = self.a
+        rvec, rn, nb = self._pairs()
+        gw = _gradW(rvec, rn, self.h, self.kd)
+        vij = (a["v"][:, None, :] - a["v"][None, :, :]).astype(f32)
+        term = a["m_V"][None, :] * (vij * gw).sum(axis=2, dtype=f32)
+        return np.where(nb, term, f32(0)).sum(axis=1, dtype=f32), nb.sum(axis=1)
+
+    def dfsph_density_change(self):
+        div, cnt = self.dfsph_velocity_divergence()
+        adv = np.where(cnt < 20, f32(0), np.maximum(div, f32(0)))
+        return np.where(self.a["material"] == 1, adv, f32(0)).astype(f32)
+
+    def dfsph_density_adv(self):
+        div, _ = self.dfsph_velocity_divergence()
+        adv = np.maximum(self.a["density"] / self.rho0 + self.dt * div, f32(1.0))
+        return np.where(self.a["material"] == 1, adv, f32(0)).astype(f32)
 
     def step(self):
         self.boundary_volume(dynamic=True)

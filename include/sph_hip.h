@@ -115,7 +115,13 @@ enum SphOption {
     SPH_OPT_DEBUG_ABLATE = 5,  /* profiling only: bit mask of sweep sections to skip (results are then wrong) */
     SPH_OPT_SLAB_DROP_OUTSIDE = 6 /* slab ranks: a particle whose x cell layer is outside the local grid is hashed to
                                   a virtual cell G (sorted behind every real cell) instead of being clamped; the
-                                  host then truncates the particle set with sph_truncate */
+                                  host then truncates the particle set with sph_truncate */,
+    SPH_OPT_UNIFORM_FLUID = 7  /* fused force sweep with ONE neighbour gather per pair instead of two.  Exact, but only
+                                  valid when every fluid particle has the same mass m and m_V == m_V0 (what the
+                                  reference's add_particle produces for scenes whose fluid blocks share one density).
+                                  -1 (default) = check on the device whenever m / m_V / material were uploaded or the
+                                  particle set changed, and use it when it holds; 0 = never; 1 = check once, then the
+                                  caller vouches for later arrivals (slab ranks: migrating particles of the same scene) */
 };
 
 /* ms accumulated by sph_step since the last sph_reset_timings (HIP events on

@@ -44,6 +44,8 @@ DevView sph_view(const SphContext* c) {
     d.eos = c->eos; d.acc = c->acc + o; d.cell_end = c->cell_end;
     d.x0_cold = c->x0_cold; d.rigid_rest_cm = c->rigid_rest_cm;
     d.m_eps = c->df.m_eps;
+    d.stg = c->stg; d.gat = c->gat;
+    d.m_u = c->m_uniform; d.write_sg = 0;
     return d;
 }
 
@@ -118,6 +120,8 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
         rc = rc ? rc : alloc_dev(c, (void**)&c->key[s], cap * 4);
     }
     rc = rc ? rc : alloc_dev(c, (void**)&c->eos, cap * 16);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->stg, cap * 16);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->gat, cap * 16);
     rc = rc ? rc : alloc_dev(c, (void**)&c->acc, cap * 16);
     rc = rc ? rc : alloc_dev(c, (void**)&c->acc_tmp, cap * 16);
     rc = rc ? rc : alloc_dev(c, (void**)&c->cell_end, (size_t)c->scan_blocks * SCAN_TILE * 4);
@@ -161,6 +165,7 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     }
     c->n_dyn_host = -1;  // unknown until material / is_dynamic are uploaded
     sph_invalidate_lists(c);
+    c->opt_uniform = -1; c->uniform_state = -1; c->m_uniform = 0.0f;  // SPH_OPT_UNIFORM_FLUID: auto
     memset(&c->df_stats, 0, sizeof(c->df_stats));
     c->df.enable_divergence_solver = 1; c->df.m_max_iterations_v = 100; c->df.m_max_iterations = 100;  // DFSPH.py:12-20
     c->df.fluid_particle_num = 0; c->df.m_eps = 1e-5f; c->df.reserved_ = 0.0f; c->df.max_error_V = 0.1; c->df.max_error = 0.05;
@@ -172,7 +177,7 @@ int32_t sph_destroy(SphContext* c) {
     if (!c) return 0;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* ptrs[] = {c->xm[0], c->xm[1], c->vf[0], c->vf[1], c->aux[0], c->aux[1], c->key[0], c->key[1], c->eos, c->acc,
+    void* ptrs[] = {c->xm[0], c->xm[1], c->vf[0], c->vf[1], c->aux[0], c->aux[1], c->key[0], c->key[1], c->eos, c->stg, c->gat, c->acc,
                     c->acc_tmp, c->cell_end, c->rank_off, c->idx_unstable, c->scan_sums, c->x0_cold, c->color_cold,
                     c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->rigid_part, c->rigid_R, c->df_err, c->df_part, c->stage, c->glist, c->gcnt, c->brick_list, c->brick_count};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -197,6 +202,7 @@ int32_t sph_set_option(SphContext* c, int32_t option, int32_t value) {
         case SPH_OPT_NO_DYNAMIC_SOLIDS: c->opt_no_dynamic = value ? 1 : 0; c->n_dyn_host = -1; return 0;
         case SPH_OPT_DEBUG_ABLATE: c->opt_ablate = value; return 0;
         case SPH_OPT_SLAB_DROP_OUTSIDE: c->opt_drop_outside = value ? 1 : 0; return 0;
+        case SPH_OPT_UNIFORM_FLUID: if (value < -1 || value > 1) return sph_fail(c, SPH_E_INVALID, "uniform-fluid option must be -1, 0 or 1"); c->opt_uniform = value; c->uniform_state = -1; return 0;
     }
     return sph_fail(c, SPH_E_INVALID, "unknown option");
 }
@@ -266,6 +272,7 @@ int32_t sph_upload(SphContext* c, int32_t field, const void* host, size_t bytes)
     if (rc) return rc;
     SPH_HIP(c, hipStreamSynchronize(c->stream));  // host buffer is only borrowed for the call
     if (field == SPH_F_MATERIAL || field == SPH_F_IS_DYNAMIC) c->n_dyn_host = -1;
+    if (field == SPH_F_MATERIAL || field == SPH_F_M || field == SPH_F_M_V) c->uniform_state = -1;
     if (field == SPH_F_X) c->have_keys = c->have_prefix = false;
     return 0;
 }
@@ -445,13 +452,26 @@ static int harvest_events(SphContext* c) {
     return 0;
 }
 
+// uniform-fluid force path: decide (once per change of the particle set) whether its precondition holds
+static int uniform_fluid(SphContext* c) {
+    // (a slab rank with dynamic solids computes forces on its first ghost layer too, whose neighbours in the outer
+    // ghost layer get no stg / gat records from the density sweep: general path there)
+    if (c->opt_uniform == 0 || c->opt_gather_impl != 1 || (c->opt_drop_outside && !c->opt_no_dynamic)) {
+        c->uniform_state = 0;
+        return 0;
+    }
+    if (c->uniform_state >= 0) return 0;
+    return sphk_check_uniform_fluid(c);
+}
+
 // sweeps of one step after the sort; ev (nullable) = the step's 5 events, ev[1] already recorded
 static int step_sweeps(SphContext* c, hipEvent_t* ev, const int32_t* dynamic_ids, int32_t n_dynamic) {
     int rc = 0;
     // compute_moving_boundary_volume()                     sph_base.py:265
     if (c->n_dyn_host > 0) { rc = sphk_gather(c, GM_BVOL_DYNAMIC); if (rc) return rc; }
     if (c->opt_fused) {
-        rc = sphk_gather(c, GM_DENSITY_EOS);                // WCSPH.py:153 (+ EOS of :74-76)
+        rc = uniform_fluid(c);
+        rc = rc ? rc : sphk_gather(c, GM_DENSITY_EOS);      // WCSPH.py:153 (+ EOS of :74-76)
         if (rc) return rc;
         if (ev) SPH_HIP(c, hipEventRecord(ev[2], c->stream));
         rc = sphk_gather(c, GM_FORCE_FUSED);                // WCSPH.py:154-155
@@ -615,6 +635,7 @@ int32_t sph_append_records(SphContext* c, const void* src, int32_t count) {
     SPH_HIP(c, hipMemcpyAsync(c->vf[c->cur] + o, s + b, b, hipMemcpyDeviceToDevice, c->stream));
     SPH_HIP(c, hipMemcpyAsync(c->aux[c->cur] + o, s + 2 * b, b, hipMemcpyDeviceToDevice, c->stream));
     c->N += count;
+    if (c->opt_uniform != 1) c->uniform_state = -1;  // arrivals are unchecked unless the caller vouches for them
     sph_invalidate_lists(c);
     c->have_keys = c->have_prefix = c->sorted = false;
     c->n_dyn_host = -1;
@@ -664,6 +685,7 @@ int32_t sph_slab_advance(SphContext* c, int32_t keep_first, int32_t keep_count, 
     if (!rc && do_sweeps == 1) rc = sph_sweeps(c);
     if (!rc && do_sweeps == 2) {  // boundary volume + density only; sph_slab_forces does the rest
         rc = refresh_dyn(c);
+        rc = rc ? rc : uniform_fluid(c);
         if (!rc && c->n_dyn_host > 0) rc = sphk_gather(c, GM_BVOL_DYNAMIC);
         rc = rc ? rc : sphk_gather(c, GM_DENSITY_EOS);
     }
@@ -700,6 +722,7 @@ int32_t sph_slab_density(SphContext* c) {
     ENTER(c);
     int rc = need_sorted(c, "sph_slab_density");
     rc = rc ? rc : refresh_dyn(c);
+    rc = rc ? rc : uniform_fluid(c);
     if (!rc && c->n_dyn_host > 0) rc = sphk_gather(c, GM_BVOL_DYNAMIC);
     return rc ? rc : sphk_gather(c, GM_DENSITY_EOS);
 }

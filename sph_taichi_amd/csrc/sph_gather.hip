@@ -53,8 +53,11 @@ __device__ __forceinline__ bool mode_needs_B() {
 template <int MODE>
 __device__ __forceinline__ bool mode_needs_C() {
     return MODE == GM_NONPRESSURE || MODE == GM_PRESSURE || MODE == GM_FORCE_FUSED || mode_is_df_iter<MODE>() ||
-           MODE == GM_DF_NONPRESSURE;
+           MODE == GM_DF_NONPRESSURE;  // (GM_FORCE_FUSED_U: no -- that is its point)
 }
+// the exact cell walk of a mode (overflow fallback): the uniform-fluid force sweep falls back to the general one
+template <int MODE>
+__host__ __device__ constexpr int mode_walk() { return MODE == GM_FORCE_FUSED_U ? GM_FORCE_FUSED : MODE; }
 
 // is particle (flags) a gather target of this mode?
 template <int MODE>
@@ -80,7 +83,8 @@ __device__ __forceinline__ float4 make_C_from_aux(const float4 aux) {
 template <int MODE>
 __device__ __forceinline__ float4 target_load_E(const DevView& d, int i) {
     if (MODE == GM_NONPRESSURE || MODE == GM_PRESSURE) return d.aux[i];
-    if (MODE == GM_FORCE_FUSED || mode_is_df_iter<MODE>() || MODE == GM_DF_DENSITY_ADV || MODE == GM_DF_NONPRESSURE)
+    if (MODE == GM_FORCE_FUSED || MODE == GM_FORCE_FUSED_U || mode_is_df_iter<MODE>() || MODE == GM_DF_DENSITY_ADV ||
+        MODE == GM_DF_NONPRESSURE)
         return d.eos[i];
     return make_float4(0.f, 0.f, 0.f, 0.f);
 }
@@ -101,10 +105,11 @@ __device__ __forceinline__ void target_init(const DevView& d, Target& t, const f
         t.st_c = d.sigma / E.x;     // WCSPH.py:100
         t.dpj_solid = E.z / (d.rho0 * d.rho0);
     }
-    if (MODE == GM_FORCE_FUSED) {
+    if (MODE == GM_FORCE_FUSED || MODE == GM_FORCE_FUSED_U) {
         t.dpi = E.x; t.m = E.z; t.rho = E.w;
         t.p = E.x * (E.w * E.w);
         t.st_c = d.sigma / E.z;
+        if (MODE == GM_FORCE_FUSED_U) t.st_c = t.st_c * d.m_u;  // (sigma / m_i) * m_j with the common m_j (WCSPH.py:100)
         t.dpj_solid = t.p / (d.rho0 * d.rho0);
     }
     if (MODE == GM_BVOL_STATIC || MODE == GM_BVOL_DYNAMIC) t.s0 = d.w_zero;  // sph_base.py:95, 110
@@ -175,13 +180,39 @@ __device__ __forceinline__ void pair_physics(const DevView& d, Target& t, float 
         t.s0 += A.w * sph_W_q(d, q);
         return;
     }
-    const int fj = __float_as_int(B.w);
+    const int fj = __float_as_int(B.w);  // (GM_FORCE_FUSED_U: B.w is not the flag word, fj unused)
     if (MODE == GM_BVOL_STATIC || MODE == GM_BVOL_DYNAMIC) {
         if (sph_flags_material(fj) == SPH_MATERIAL_SOLID) t.s0 += sph_W_q(d, q);  // sph_base.py:100-103
         return;
     }
     const bool j_fluid = sph_is_fluid(fj);
     const float gc = sph_gradW_coef(d, q, r_norm, rinv);
+    if (MODE == GM_FORCE_FUSED_U) {
+        // A = (x_j, U_j), B = (v_j, p_j/rho_j^2) for a fluid neighbour (U = m_j/rho_raw_j > 0; m_j = m_u, m_V_j = m_V0);
+        // for a solid one U = -m_V_j and B.w = 1 if it is dynamic.  Same formulas as GM_FORCE_FUSED below.
+        if (A.w > 0.0f) {
+            const float w = (r2 > d.d2) ? sph_W_q(d, q) : d.w_d;
+            const float c = t.st_c * w;                                           // WCSPH.py:93-102
+            const float v_xy = (t.vx - B.x) * rx + (t.vy - B.y) * ry + (t.vz - B.z) * rz;
+            const float cv = d.visc_d_nu * A.w * v_xy * sph_rcp(r2 + d.visc_eps) * gc;  // WCSPH.py:105-116
+            const float k = cv - c;
+            t.ax += k * rx; t.ay += k * ry; t.az += k * rz;
+            const float cp = -d.rho0 * d.m_V0 * (t.dpi + B.w) * gc;                // WCSPH.py:51-57
+            t.px += cp * rx; t.py += cp * ry; t.pz += cp * rz;
+        } else {
+            const float cp = -d.rho0 * (-A.w) * (t.dpi + t.dpj_solid) * gc;        // WCSPH.py:58-68
+            const float fx = cp * rx, fy = cp * ry, fz = cp * rz;
+            t.px += fx; t.py += fy; t.pz += fz;
+            if (B.w != 0.0f) {
+                const float sc = d.rho0 * sph_rcp(d.aux[gj].y);  // density[p_j] of the body particle
+                float* a = reinterpret_cast<float*>(&d.acc[gj]);
+                unsafeAtomicAdd(a + 0, -fx * sc);
+                unsafeAtomicAdd(a + 1, -fy * sc);
+                unsafeAtomicAdd(a + 2, -fz * sc);
+            }
+        }
+        return;
+    }
     // ---- DFSPH: grad_p_j = -m_V_j gradW(x_i - x_j) = -(c rx, c ry, c rz) with c = m_V_j * gc ----
     if (MODE == GM_DF_FACTOR) {
         const float c = A.w * gc;
@@ -292,6 +323,11 @@ __device__ __forceinline__ void target_finish(const DevView& d, Target& t, int i
             d.acc[i] = st ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(d.gx, d.gy, d.gz, 0.f);
         }
         d.eos[i] = e;
+        if (d.write_sg) {  // records of the uniform-fluid force sweep (positions do not change before it runs)
+            const bool fl = sph_is_fluid(t.flags);
+            d.stg[i] = make_float4(t.x, t.y, t.z, fl ? e.y : -t.mV);
+            d.gat[i] = make_float4(t.vx, t.vy, t.vz, fl ? e.x : (sph_is_dynamic_rigid(t.flags) ? 1.0f : 0.0f));
+        }
         return;
     }
     if (MODE == GM_NONPRESSURE || MODE == GM_DF_NONPRESSURE) {
@@ -347,7 +383,7 @@ __device__ __forceinline__ void target_finish(const DevView& d, Target& t, int i
         }
         return;
     }
-    if (MODE == GM_FORCE_FUSED) {
+    if (MODE == GM_FORCE_FUSED || MODE == GM_FORCE_FUSED_U) {
         // fluid: a = (g + non-pressure) + pressure  (WCSPH.py:140 then :85)
         if (gathered) d.acc[i] = make_float4(t.ax + t.px, t.ay + t.py, t.az + t.pz, 0.f);
         return;
@@ -630,7 +666,7 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
 #pragma unroll
             for (int step = 16; step > 0; step >>= 1)
                 if (sColS[col + step] <= idx) col += step;
-            buf[u] = d.xm[sColG[col] + idx];
+            buf[u] = (MODE == GM_FORCE_FUSED_U ? d.stg : d.xm)[sColG[col] + idx];
         }
 #pragma unroll
         for (int u = 0; u < CFG::PER; ++u) {
@@ -770,7 +806,7 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
                 s_.A = sQ[s_.j];  // list-reading sweeps: (x, y, z, m_V)
                 if (HAS_W) s_.A.w = sW[s_.j];
                 s_.g = sColG[e >> 11] + s_.j;
-                s_.B = mode_needs_B<MODE>() ? d.vf[s_.g] : make_float4(0.f, 0.f, 0.f, 0.f);
+                s_.B = mode_needs_B<MODE>() ? (MODE == GM_FORCE_FUSED_U ? d.gat : d.vf)[s_.g] : make_float4(0.f, 0.f, 0.f, 0.f);
                 s_.C = mode_needs_C<MODE>() ? load_C_global<MODE>(d, s_.g) : make_float4(0.f, 0.f, 0.f, 0.f);
             };
             auto pair = [&](const Slot& s_) {
@@ -805,8 +841,8 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
             }
         }
         if (walk) {
-            target_init<MODE>(d, t, Ai, Bi, Ei);
-            gather_walk_global<MODE>(d, t, gi);
+            target_init<mode_walk<MODE>()>(d, t, Ai, Bi, Ei);
+            gather_walk_global<mode_walk<MODE>()>(d, t, gi);
         }
         target_finish<MODE>(d, t, gi, g);
     }
@@ -844,8 +880,8 @@ static int launch_simple(SphContext* c, const int* list, int n) {
 template <int MODE, class CFG>
 static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, int hi2 = 0) {
     DevView d = sph_view(c);
-    if (MODE == GM_DENSITY_EOS) { d.tgt_lo = c->tgt_layers[0]; d.tgt_hi = c->tgt_layers[1]; }
-    if (MODE == GM_FORCE_FUSED) { d.tgt_lo = c->tgt_layers[2]; d.tgt_hi = c->tgt_layers[3]; }
+    if (MODE == GM_DENSITY_EOS) { d.tgt_lo = c->tgt_layers[0]; d.tgt_hi = c->tgt_layers[1]; d.write_sg = c->uniform_state == 1; }
+    if (MODE == GM_FORCE_FUSED || MODE == GM_FORCE_FUSED_U) { d.tgt_lo = c->tgt_layers[2]; d.tgt_hi = c->tgt_layers[3]; }
     if (lo >= 0) { d.tgt_lo = lo; d.tgt_hi = hi; d.tgt_lo2 = lo2; d.tgt_hi2 = hi2; }
     if (d.tgt_hi2 <= d.tgt_lo2) d.tgt_lo2 = d.tgt_hi2 = 0;
     if (d.tgt_hi <= d.tgt_lo) { d.tgt_lo = d.tgt_lo2; d.tgt_hi = d.tgt_hi2; d.tgt_lo2 = d.tgt_hi2 = 0; }
@@ -894,6 +930,7 @@ int sphk_gather_layers(SphContext* c, int mode, int lo, int hi, int lo2, int hi2
     if (c->N <= 0 || (hi <= lo && hi2 <= lo2)) return 0;
     if (mode != GM_FORCE_FUSED || c->opt_gather_impl == 0) return sph_fail(c, SPH_E_INVALID, "layer-restricted sweeps need the brick force kernel");
     if (hi < lo) hi = lo;
+    if (c->uniform_state == 1 && c->lists_valid && c->sg_valid) return launch_brick<GM_FORCE_FUSED_U>(c, lo, hi, lo2, hi2);
     return launch_brick<GM_FORCE_FUSED>(c, lo, hi, lo2, hi2);
 }
 
@@ -903,6 +940,7 @@ static int launch_sweep(SphContext* c) {
     if (c->opt_gather_impl == 0) return launch_simple<MODE>(c, nullptr, c->N);
     int rc = launch_brick<MODE>(c);
     if (!rc && mode_writes_list<MODE>()) c->lists_valid = true;
+    if (!rc && MODE == GM_DENSITY_EOS) c->sg_valid = c->uniform_state == 1;
     return rc;
 }
 
@@ -933,7 +971,12 @@ int sphk_gather(SphContext* c, int mode) {
         case GM_DENSITY_EOS: return launch_sweep<GM_DENSITY_EOS>(c);
         case GM_NONPRESSURE: return launch_sweep<GM_NONPRESSURE>(c);
         case GM_PRESSURE: return launch_sweep<GM_PRESSURE>(c);
-        case GM_FORCE_FUSED: return launch_sweep<GM_FORCE_FUSED>(c);
+        case GM_FORCE_FUSED:
+            // one gather per pair when every fluid particle has the same mass (and the density sweep of this step
+            // left its stg / gat records): see SPH_OPT_UNIFORM_FLUID
+            if (c->uniform_state == 1 && c->opt_gather_impl == 1 && c->lists_valid && c->sg_valid && c->N > 0)
+                return launch_brick<GM_FORCE_FUSED_U>(c);
+            return launch_sweep<GM_FORCE_FUSED>(c);
         case GM_DF_DENSITY: return launch_df<GM_DF_DENSITY>(c);
         case GM_DF_FACTOR: return launch_df<GM_DF_FACTOR>(c);
         case GM_DF_DENSITY_CHANGE: return launch_df<GM_DF_DENSITY_CHANGE>(c);

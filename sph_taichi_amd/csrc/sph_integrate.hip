@@ -55,6 +55,33 @@ __global__ __launch_bounds__(TPB) void k_advect(DevView d, WallHi hi) {
     d.vf[i] = vf;
 }
 
+// Precondition of the uniform-fluid force path: every fluid particle has the same mass and m_V == m_V0 (bitwise).
+// out[0] = min, out[1] = max of the mass bit patterns (positive floats order like unsigned ints), out[2] = number of
+// fluid particles whose m_V differs from m_V0, out[3] = number of fluid particles.
+__global__ __launch_bounds__(TPB) void k_check_uniform(DevView d, unsigned* __restrict__ out) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    unsigned lo = 0xFFFFFFFFu, hi = 0u;
+    int bad = 0, nf = 0;
+    if (i < d.N && sph_is_fluid(__float_as_int(d.vf[i].w))) {
+        lo = hi = __float_as_uint(d.aux[i].x);
+        bad = __float_as_uint(d.xm[i].w) != __float_as_uint(d.m_V0) ? 1 : 0;
+        nf = 1;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, (unsigned)__shfl_down((int)lo, off, 64));
+        hi = max(hi, (unsigned)__shfl_down((int)hi, off, 64));
+        bad += __shfl_down(bad, off, 64);
+        nf += __shfl_down(nf, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && nf > 0) {
+        atomicMin(&out[0], lo);
+        atomicMax(&out[1], hi);
+        atomicAdd(&out[2], (unsigned)bad);
+        atomicAdd(&out[3], (unsigned)nf);
+    }
+}
+
 // ---- DFSPH element-wise kernels (eos record = (dfsph_factor, density_adv, m, density)) ----
 // DFSPH.py:388-394 predict_velocity
 __global__ __launch_bounds__(TPB) void k_df_predict_velocity(DevView d) {
@@ -758,5 +785,25 @@ int sphk_df_density_error(SphContext* c, float offset, float* out_host) {
         h = *(volatile double*)c->h_df_err;
     }
     *out_host = (float)h;
+    return 0;
+}
+
+int sphk_check_uniform_fluid(SphContext* c) {
+    c->uniform_state = 0;
+    c->m_uniform = 0.0f;
+    if (c->N <= 0) return 0;
+    DevView d = sph_view(c);
+    unsigned* out = reinterpret_cast<unsigned*>(c->stage);  // 16 bytes of the staging buffer
+    const unsigned init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
+    unsigned h[4];
+    SPH_HIP(c, hipMemcpyAsync(out, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_check_uniform, dim3((c->N + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, out);
+    SPH_LAUNCH_CHECK(c);
+    SPH_HIP(c, hipMemcpyAsync(h, out, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    SPH_HIP(c, hipStreamSynchronize(c->stream));
+    if (h[3] > 0 && h[0] == h[1] && h[2] == 0) {
+        memcpy(&c->m_uniform, &h[0], sizeof(float));
+        c->uniform_state = c->m_uniform > 0.0f ? 1 : 0;
+    }
     return 0;
 }

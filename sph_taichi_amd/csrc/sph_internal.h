@@ -42,10 +42,14 @@ struct DevView {
     float k_w, k_dw, visc_d_nu, visc_eps;
     float w_zero, w_d;  // W(0), W(d)
     float m_eps;        // DFSPH.py:17
+    float m_u;          // the common fluid particle mass (uniform-fluid force path)
+    int write_sg;       // density+EOS finish also writes the stg / gat records of that path
     float4* xm;
     float4* vf;
     float4* aux;
     float4* eos;
+    float4* stg;  // (x, y, z, U): U = m/rho_raw (fluid, > 0) or -m_V (solid)      } uniform-fluid force path:
+    float4* gat;  // (vx, vy, vz, p/rho^2) (fluid) or (v, 1 if dynamic else 0) (solid) } staged / gathered records
     float4* acc;
     int* key;
     int* cell_end;
@@ -74,6 +78,8 @@ struct SphContext {
     float4* aux[2];
     int* key[2];
     float4* eos;
+    float4* stg;
+    float4* gat;
     float4* acc;
     float4* acc_tmp;
     int* cell_end;     // [G+1]
@@ -99,6 +105,7 @@ struct SphContext {
     size_t stage_bytes;
     bool have_keys, have_prefix, sorted;
     bool lists_valid;   // glist/gcnt describe the CURRENT positions and order (written by a list-writing brick sweep)
+    bool sg_valid;      // stg / gat were written by the density+EOS sweep for the current positions
     bool bricks_valid;  // brick_list/brick_count describe the current order for the target ranges in bricks_key
     int bricks_key[5];  // brick shape id, tgt_lo, tgt_hi, tgt_lo2, tgt_hi2
     double* h_df_err;   // pinned, device-visible: result of compute_density_error
@@ -108,6 +115,9 @@ struct SphContext {
     double* df_err;     // device accumulator of compute_density_error
     // options
     int opt_gather_impl, opt_timing, opt_fused, opt_brick_shape, opt_no_dynamic, opt_ablate, opt_drop_outside;
+    int opt_uniform;     // SPH_OPT_UNIFORM_FLUID: -1 auto, 0 off, 1 check once
+    int uniform_state;   // -1 unknown, 0 the precondition fails, 1 holds (m_uniform valid)
+    float m_uniform;
     // timing
     hipEvent_t ev[SPH_MAX_TIMED_STEPS][5];
     int ev_used;
@@ -117,7 +127,7 @@ struct SphContext {
 
 DevView sph_view(const SphContext* c);
 // particle positions / order / flags changed: neighbour lists and the non-empty-brick list are stale
-static inline void sph_invalidate_lists(SphContext* c) { c->lists_valid = false; c->bricks_valid = false; }
+static inline void sph_invalidate_lists(SphContext* c) { c->lists_valid = false; c->bricks_valid = false; c->sg_valid = false; }
 int sph_fail(SphContext* c, int code, const char* what);
 
 #define SPH_HIP(ctx, expr)                                                        \
@@ -143,6 +153,7 @@ int sphk_gather(SphContext* c, int mode);
 int sphk_gather_layers(SphContext* c, int mode, int lo, int hi, int lo2, int hi2);  // brick sweep, targets in x layers [lo,hi) u [lo2,hi2)
 int sphk_pack_advected(SphContext* c, int first, int count, void* dst);
 int sphk_eos(SphContext* c);
+int sphk_check_uniform_fluid(SphContext* c);  // sets uniform_state / m_uniform (synchronises)
 int sphk_df_density_error(SphContext* c, float offset, float* out_host);
 int sphk_df_scale_factor(SphContext* c, float s);
 int sphk_df_predict_velocity(SphContext* c);
@@ -169,7 +180,8 @@ enum GatherMode {
     GM_DF_DENSITY_ADV = 10,    // DFSPH.py:200-221
     GM_DF_DIV_ITER = 11,       // DFSPH.py:285-321
     GM_DF_PRESSURE_ITER = 12,  // DFSPH.py:356-394
-    GM_DF_NONPRESSURE = 13     // DFSPH.py:49-97
+    GM_DF_NONPRESSURE = 13,    // DFSPH.py:49-97
+    GM_FORCE_FUSED_U = 14      // GM_FORCE_FUSED for fluids of one common particle mass: one gather per pair
 };
 
 #ifdef __HIPCC__

@@ -121,7 +121,8 @@ enum SphOption {
                                   reference's add_particle produces for scenes whose fluid blocks share one density).
                                   -1 (default) = check on the device whenever m / m_V / material were uploaded or the
                                   particle set changed, and use it when it holds; 0 = never; 1 = check once, then the
-                                  caller vouches for later arrivals (slab ranks: migrating particles of the same scene) */
+                                  caller vouches for later arrivals (slab ranks: migrating particles of the same scene) */,
+    SPH_OPT_UNIFORM_FLUID_STATE = 8 /* read-only (sph_get_option): -1 not decided yet, 0 general sweep, 1 one-gather sweep */
 };
 
 /* ms accumulated by sph_step since the last sph_reset_timings (HIP events on

@@ -215,6 +215,10 @@ int32_t sph_get_option(const SphContext* c, int32_t option, int32_t* value) {
         case SPH_OPT_FUSED_STEP: *value = c->opt_fused; return 0;
         case SPH_OPT_BRICK_SHAPE: *value = c->opt_brick_shape; return 0;
         case SPH_OPT_NO_DYNAMIC_SOLIDS: *value = c->opt_no_dynamic; return 0;
+        case SPH_OPT_DEBUG_ABLATE: *value = c->opt_ablate; return 0;
+        case SPH_OPT_SLAB_DROP_OUTSIDE: *value = c->opt_drop_outside; return 0;
+        case SPH_OPT_UNIFORM_FLUID: *value = c->opt_uniform; return 0;
+        case SPH_OPT_UNIFORM_FLUID_STATE: *value = c->uniform_state; return 0;
     }
     return SPH_E_INVALID;
 }

@@ -195,6 +195,10 @@ class SlabSolver:
         self.ps.set_option(_lib.OPT_BRICK_SHAPE, brick_shape)
         self.ps.set_option(_lib.OPT_NO_DYNAMIC_SOLIDS, 0 if self.has_dynamic else 1)
         self.ps.set_option(_lib.OPT_SLAB_DROP_OUTSIDE, 1)
+        # one-gather force sweep: the host knows whether every fluid block has the same density (=> one particle
+        # mass); then the device checks the local particles once and later arrivals are vouched for
+        same_mass = len({float(b["density"]) for b in cfg.get_fluid_blocks()}) <= 1
+        self.ps.set_option(_lib.OPT_UNIFORM_FLUID, 1 if same_mass else 0)
         nxl = self.x_hi - self.x_lo + 2 * halo
         # targets: density on owned + ghost layer 1 (its rho/p feed the owned forces); forces on owned only,
         # or also on ghost layer 1 when dynamic solids exist (their owner accumulates the coupling reaction

@@ -169,6 +169,12 @@ class ParticleSystem:
     def set_option(self, option: int, value: int):
         self._call("sph_set_option", int(option), int(value))
 
+    def get_option(self, option: int) -> int:
+        v = C.c_int32()
+        rc = self._lib.sph_get_option(self._ctx, int(option), C.byref(v))
+        _lib.check(self._lib, self._ctx, rc, "sph_get_option")
+        return int(v.value)
+
     def sync(self):
         self._call("sph_sync")
 

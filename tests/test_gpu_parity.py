@@ -419,3 +419,49 @@ def test_api_misuse_and_degenerate_scenes():
     o.initialize(); solver.initialize(); o.step(3); solver.step(3)
     assert scenes.rel_l2(scenes.ps_by_pid(ps, "x"), o.by_pid("x")) <= 1e-6
     ps.close()
+
+
+@pytest.mark.parametrize("uniform", [0, -1])
+def test_force_paths_general_and_uniform(uniform):
+    """SPH_OPT_UNIFORM_FLUID: the one-gather force sweep (auto: all fluid masses equal) and the general two-gather
+    sweep (forced with 0) follow the oracle alike; kernel by kernel for the coupled scene."""
+    from sph_taichi_amd import _lib
+    sd = scenes.fluid_with_rigid_blocks()
+    cfg, sc = scenes.build(sd)
+    scenes.jitter(sc, 0.1, seed=4)
+    o = scenes.make_oracle(cfg, sc)
+    ps, solver = scenes.make_ps(sd, sc.arrays)
+    ps.set_option(_lib.OPT_UNIFORM_FLUID, uniform)
+    o.initialize(); solver.initialize()
+    o.step(20); solver.step(20)
+    assert ps.get_option(_lib.OPT_UNIFORM_FLUID_STATE) == (1 if uniform == -1 else 0)
+    assert scenes.rel_l2(scenes.ps_by_pid(ps, "x"), o.by_pid("x")) <= 1e-4
+    _cmp("acceleration", scenes.ps_by_pid(ps, "acceleration"), o.by_pid("acceleration"), 2e-3)
+    ps.close()
+
+
+def test_two_fluid_densities_use_the_general_force_sweep():
+    """Fluid blocks of different density => different particle masses => the uniform-fluid precondition fails and the
+    automatic check must fall back to the general sweep (the one-gather sweep would use the wrong m_j)."""
+    sd = scenes.fluid_only(counts=(10, 10, 8), start=(0.1, 0.1, 0.1))
+    second = dict(sd["FluidBlocks"][0])
+    second.update(objectId=1, start=[0.34, 0.1, 0.1], end=scenes.lattice_end((0.34, 0.1, 0.1), (8, 10, 8)), density=600.0,
+                  velocity=[-1.5, -1.0, 0.0])
+    sd["FluidBlocks"].append(second)
+    cfg, sc = scenes.build(sd)
+    assert len(np.unique(sc.arrays["m"])) == 2
+    o = scenes.make_oracle(cfg, sc)
+    ps, solver = scenes.make_ps(sd)
+    o.initialize(); solver.initialize()
+    o.step(25); solver.step(25)
+    from sph_taichi_amd import _lib
+    assert ps.get_option(_lib.OPT_UNIFORM_FLUID_STATE) == 0
+    assert scenes.rel_l2(scenes.ps_by_pid(ps, "x"), o.by_pid("x")) <= 1e-4
+    assert scenes.rel_l2(scenes.ps_by_pid(ps, "v"), o.by_pid("v")) <= 2e-3
+    # a fluid whose m_V was edited by hand also disqualifies the fast sweep
+    ps2, solver2 = scenes.make_ps(scenes.fluid_only())
+    mv = ps2.m_V.to_numpy(); mv[3] *= 1.01; ps2.m_V.from_numpy(mv)
+    solver2.initialize(); solver2.step(2)
+    assert ps2.get_option(_lib.OPT_UNIFORM_FLUID_STATE) == 0
+    ps2.close()
+    ps.close()

@@ -44,8 +44,8 @@ DevView sph_view(const SphContext* c) {
     d.eos = c->eos; d.acc = c->acc + o; d.cell_end = c->cell_end;
     d.x0_cold = c->x0_cold; d.rigid_rest_cm = c->rigid_rest_cm;
     d.m_eps = c->df.m_eps;
-    d.stg = c->stg; d.gat = c->gat;
-    d.m_u = c->m_uniform; d.write_sg = 0;
+    d.stg = c->stg; d.gat = c->gat; d.kbuf = reinterpret_cast<float*>(c->gat);
+    d.m_u = c->m_uniform; d.write_sg = 0; d.write_k = 0;
     return d;
 }
 
@@ -826,11 +826,13 @@ int32_t sph_dfsph_divergence_solve(SphContext* c) {
     ENTER(c);
     int rc = need_sorted(c, "sph_dfsph_divergence_solve");
     rc = rc ? rc : refresh_dyn(c);
-    rc = rc ? rc : sphk_gather(c, GM_DF_DENSITY_CHANGE);
     if (rc) return rc;
     const double dt = (double)c->p.dt;
     const double inv_dt = 1 / dt;
+    // (compute_density_change does not read the factor, so scaling it first changes nothing -- and lets that sweep
+    // leave k_j = density_adv_j * factor_j behind for the Jacobi sweep)
     rc = sphk_df_scale_factor(c, (float)inv_dt);
+    rc = rc ? rc : sphk_gather(c, GM_DF_DENSITY_CHANGE);
     if (rc) return rc;
     int m_iterations_v = 0;
     double avg_density_err = 0.0;
@@ -859,8 +861,8 @@ int32_t sph_dfsph_pressure_solve(SphContext* c) {
     if (rc) return rc;
     const double dt = (double)c->p.dt;
     const double inv_dt2 = 1 / (dt * dt);
-    rc = sphk_gather(c, GM_DF_DENSITY_ADV);
-    rc = rc ? rc : sphk_df_scale_factor(c, (float)inv_dt2);
+    rc = sphk_df_scale_factor(c, (float)inv_dt2);          // (before compute_density_adv, see divergence_solve)
+    rc = rc ? rc : sphk_gather(c, GM_DF_DENSITY_ADV);
     if (rc) return rc;
     int m_iterations = 0;
     double avg_density_err = 0.0;

@@ -43,21 +43,31 @@ struct Target {
 };
 
 template <int MODE>
-__host__ __device__ constexpr bool mode_is_df_iter() { return MODE == GM_DF_DIV_ITER || MODE == GM_DF_PRESSURE_ITER; }
+__host__ __device__ constexpr bool mode_is_df_iter_u() { return MODE == GM_DF_DIV_ITER_U || MODE == GM_DF_PRESSURE_ITER_U; }
+template <int MODE>
+__host__ __device__ constexpr bool mode_is_df_iter() {
+    return MODE == GM_DF_DIV_ITER || MODE == GM_DF_PRESSURE_ITER || mode_is_df_iter_u<MODE>();
+}
+template <int MODE>
+__host__ __device__ constexpr bool mode_is_df_pressure() { return MODE == GM_DF_PRESSURE_ITER || MODE == GM_DF_PRESSURE_ITER_U; }
 template <int MODE>
 __host__ __device__ constexpr bool mode_is_df_vdiv() { return MODE == GM_DF_DENSITY_CHANGE || MODE == GM_DF_DENSITY_ADV; }
 template <int MODE>
 __device__ __forceinline__ bool mode_needs_B() {
-    return MODE != GM_DENSITY && MODE != GM_DENSITY_EOS && MODE != GM_DF_DENSITY;
+    return MODE != GM_DENSITY && MODE != GM_DENSITY_EOS && MODE != GM_DF_DENSITY && !mode_is_df_iter_u<MODE>();
 }
 template <int MODE>
 __device__ __forceinline__ bool mode_needs_C() {
-    return MODE == GM_NONPRESSURE || MODE == GM_PRESSURE || MODE == GM_FORCE_FUSED || mode_is_df_iter<MODE>() ||
-           MODE == GM_DF_NONPRESSURE;  // (GM_FORCE_FUSED_U: no -- that is its point)
+    return MODE == GM_NONPRESSURE || MODE == GM_PRESSURE || MODE == GM_FORCE_FUSED ||
+           (mode_is_df_iter<MODE>() && !mode_is_df_iter_u<MODE>()) ||
+           MODE == GM_DF_NONPRESSURE;  // (GM_FORCE_FUSED_U: no -- that is its point; *_ITER_U: 4 bytes, see fetch)
 }
 // the exact cell walk of a mode (overflow fallback): the uniform-fluid force sweep falls back to the general one
 template <int MODE>
-__host__ __device__ constexpr int mode_walk() { return MODE == GM_FORCE_FUSED_U ? GM_FORCE_FUSED : MODE; }
+__host__ __device__ constexpr int mode_walk() {
+    return MODE == GM_FORCE_FUSED_U ? GM_FORCE_FUSED
+           : MODE == GM_DF_DIV_ITER_U ? GM_DF_DIV_ITER : MODE == GM_DF_PRESSURE_ITER_U ? GM_DF_PRESSURE_ITER : MODE;
+}
 
 // is particle (flags) a gather target of this mode?
 template <int MODE>
@@ -83,7 +93,7 @@ __device__ __forceinline__ float4 make_C_from_aux(const float4 aux) {
 template <int MODE>
 __device__ __forceinline__ float4 target_load_E(const DevView& d, int i) {
     if (MODE == GM_NONPRESSURE || MODE == GM_PRESSURE) return d.aux[i];
-    if (MODE == GM_FORCE_FUSED || MODE == GM_FORCE_FUSED_U || mode_is_df_iter<MODE>() || MODE == GM_DF_DENSITY_ADV ||
+    if (MODE == GM_FORCE_FUSED || MODE == GM_FORCE_FUSED_U || mode_is_df_iter<MODE>() || mode_is_df_vdiv<MODE>() ||
         MODE == GM_DF_NONPRESSURE)
         return d.eos[i];
     return make_float4(0.f, 0.f, 0.f, 0.f);
@@ -116,12 +126,12 @@ __device__ __forceinline__ void target_init(const DevView& d, Target& t, const f
     t.nn = 0;
     // DFSPH: E = (dfsph_factor, density_adv, m, density)
     if (MODE == GM_DF_FACTOR) t.ax = t.ay = t.az = 0.0f;  // grad_p_i (DFSPH.py:122)
-    if (MODE == GM_DF_DENSITY_ADV) t.rho = E.w;
-    if (MODE == GM_DF_DIV_ITER) {  // DFSPH.py:292-294: b_i = density_adv, k_i = b_i * factor; dv starts at 0
+    if (mode_is_df_vdiv<MODE>()) { t.rho = E.w; t.p = E.x; }  // t.p: the target's own dfsph_factor (for k_i)
+    if (MODE == GM_DF_DIV_ITER || MODE == GM_DF_DIV_ITER_U) {  // DFSPH.py:292-294: b_i = density_adv, k_i = b_i * factor; dv starts at 0
         t.dpi = E.y * E.x; t.rho = E.w;
         t.ax = t.ay = t.az = 0.0f;
     }
-    if (MODE == GM_DF_PRESSURE_ITER) {  // DFSPH.py:362-363: b_i = density_adv - 1; v[p_i] is updated pair by pair
+    if (mode_is_df_pressure<MODE>()) {  // DFSPH.py:362-363: b_i = density_adv - 1; v[p_i] is updated pair by pair
         t.dpi = (E.y - 1.0f) * E.x; t.rho = E.w;
         t.ax = B.x; t.ay = B.y; t.az = B.z;
     }
@@ -224,6 +234,29 @@ __device__ __forceinline__ void pair_physics(const DevView& d, Target& t, float 
         // DFSPH.py:183-197 / :212-221: m_V_j (v_i - v_j) . gradW, fluid and boundary neighbours alike
         t.s0 += A.w * (gc * ((t.vx - B.x) * rx + (t.vy - B.y) * ry + (t.vz - B.z) * rz));
         t.nn += 1;
+        return;
+    }
+    if (mode_is_df_iter_u<MODE>()) {
+        // A.w = +m_V_j (fluid) / -m_V_j (solid); Cc.x = k_j = b_j * factor_j.  Formulas of the general sweep below.
+        const float mV = fabsf(A.w);
+        if (A.w > 0.0f) {
+            const float k_sum = t.dpi + Cc.x;
+            if (fabsf(k_sum) > d.m_eps) {
+                const float c = (d.dt * k_sum) * (mV * gc);
+                t.ax += c * rx; t.ay += c * ry; t.az += c * rz;
+            }
+        } else if (fabsf(t.dpi) > d.m_eps) {
+            const float c = (d.dt * t.dpi) * (mV * gc);
+            const float fx = c * rx, fy = c * ry, fz = c * rz;
+            t.ax += fx; t.ay += fy; t.az += fz;
+            if (sph_is_dynamic_rigid(__float_as_int(d.vf[gj].w))) {  // solid neighbours are few: fetched only here
+                const float sc = t.rho * sph_rcp(d.eos[gj].w) * sph_rcp(d.dt);
+                float* a = reinterpret_cast<float*>(&d.acc[gj]);
+                unsafeAtomicAdd(a + 0, -fx * sc);
+                unsafeAtomicAdd(a + 1, -fy * sc);
+                unsafeAtomicAdd(a + 2, -fz * sc);
+            }
+        }
         return;
     }
     if (mode_is_df_iter<MODE>()) {
@@ -344,6 +377,7 @@ __device__ __forceinline__ void target_finish(const DevView& d, Target& t, int i
         }
         float* e = reinterpret_cast<float*>(&d.eos[i]);  // .x/.y (factor, density_adv) live until they are recomputed
         e[2] = aux.x; e[3] = aux.y;
+        if (d.write_sg) d.stg[i] = make_float4(t.x, t.y, t.z, sph_is_fluid(t.flags) ? t.mV : -t.mV);
         return;
     }
     if (MODE == GM_DF_FACTOR) {  // DFSPH.py:128-139
@@ -358,17 +392,22 @@ __device__ __forceinline__ void target_finish(const DevView& d, Target& t, int i
             float adv = fmaxf(t.s0, 0.0f);
             if (t.nn < 20) adv = 0.0f;
             reinterpret_cast<float*>(&d.eos[i])[1] = adv;
+            if (d.write_k) d.kbuf[i] = adv * t.p;  // k_i = b_i * factor_i (DFSPH.py:292-294), for the neighbours
         }
         return;
     }
     if (MODE == GM_DF_DENSITY_ADV) {  // DFSPH.py:206-209
-        if (gathered) reinterpret_cast<float*>(&d.eos[i])[1] = fmaxf(t.rho / d.rho0 + d.dt * t.s0, 1.0f);
+        if (gathered) {
+            const float adv = fmaxf(t.rho / d.rho0 + d.dt * t.s0, 1.0f);
+            reinterpret_cast<float*>(&d.eos[i])[1] = adv;
+            if (d.write_k) d.kbuf[i] = (adv - 1.0f) * t.p;  // DFSPH.py:362-363
+        }
         return;
     }
     if (mode_is_df_iter<MODE>()) {  // DFSPH.py:296 v += dv  /  :378, :387 v updated in place (t.a started at v)
         if (gathered) {
             float* v = reinterpret_cast<float*>(&d.vf[i]);  // .w (flags) is read concurrently by other lanes
-            if (MODE == GM_DF_DIV_ITER) { v[0] = t.vx + t.ax; v[1] = t.vy + t.ay; v[2] = t.vz + t.az; }
+            if (!mode_is_df_pressure<MODE>()) { v[0] = t.vx + t.ax; v[1] = t.vy + t.ay; v[2] = t.vz + t.az; }
             else { v[0] = t.ax; v[1] = t.ay; v[2] = t.az; }
         }
         return;
@@ -666,7 +705,7 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
 #pragma unroll
             for (int step = 16; step > 0; step >>= 1)
                 if (sColS[col + step] <= idx) col += step;
-            buf[u] = (MODE == GM_FORCE_FUSED_U ? d.stg : d.xm)[sColG[col] + idx];
+            buf[u] = ((MODE == GM_FORCE_FUSED_U || mode_is_df_iter_u<MODE>()) ? d.stg : d.xm)[sColG[col] + idx];
         }
 #pragma unroll
         for (int u = 0; u < CFG::PER; ++u) {
@@ -808,6 +847,7 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
                 s_.g = sColG[e >> 11] + s_.j;
                 s_.B = mode_needs_B<MODE>() ? (MODE == GM_FORCE_FUSED_U ? d.gat : d.vf)[s_.g] : make_float4(0.f, 0.f, 0.f, 0.f);
                 s_.C = mode_needs_C<MODE>() ? load_C_global<MODE>(d, s_.g) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (mode_is_df_iter_u<MODE>()) s_.C.x = d.kbuf[s_.g];  // the one 4-byte gather of these sweeps
             };
             auto pair = [&](const Slot& s_) {
                 // filtering sweeps hold x_j' = -A/2 in shell-local coordinates; list-reading sweeps hold x_j itself
@@ -881,6 +921,8 @@ template <int MODE, class CFG>
 static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, int hi2 = 0) {
     DevView d = sph_view(c);
     if (MODE == GM_DENSITY_EOS) { d.tgt_lo = c->tgt_layers[0]; d.tgt_hi = c->tgt_layers[1]; d.write_sg = c->uniform_state == 1; }
+    if (MODE == GM_DF_DENSITY) d.write_sg = 1;
+    if (mode_is_df_vdiv<MODE>()) d.write_k = 1;
     if (MODE == GM_FORCE_FUSED || MODE == GM_FORCE_FUSED_U) { d.tgt_lo = c->tgt_layers[2]; d.tgt_hi = c->tgt_layers[3]; }
     if (lo >= 0) { d.tgt_lo = lo; d.tgt_hi = hi; d.tgt_lo2 = lo2; d.tgt_hi2 = hi2; }
     if (d.tgt_hi2 <= d.tgt_lo2) d.tgt_lo2 = d.tgt_hi2 = 0;
@@ -930,7 +972,7 @@ int sphk_gather_layers(SphContext* c, int mode, int lo, int hi, int lo2, int hi2
     if (c->N <= 0 || (hi <= lo && hi2 <= lo2)) return 0;
     if (mode != GM_FORCE_FUSED || c->opt_gather_impl == 0) return sph_fail(c, SPH_E_INVALID, "layer-restricted sweeps need the brick force kernel");
     if (hi < lo) hi = lo;
-    if (c->uniform_state == 1 && c->lists_valid && c->sg_valid) return launch_brick<GM_FORCE_FUSED_U>(c, lo, hi, lo2, hi2);
+    if (c->uniform_state == 1 && c->lists_valid && c->stg_kind == 1) return launch_brick<GM_FORCE_FUSED_U>(c, lo, hi, lo2, hi2);
     return launch_brick<GM_FORCE_FUSED>(c, lo, hi, lo2, hi2);
 }
 
@@ -940,7 +982,7 @@ static int launch_sweep(SphContext* c) {
     if (c->opt_gather_impl == 0) return launch_simple<MODE>(c, nullptr, c->N);
     int rc = launch_brick<MODE>(c);
     if (!rc && mode_writes_list<MODE>()) c->lists_valid = true;
-    if (!rc && MODE == GM_DENSITY_EOS) c->sg_valid = c->uniform_state == 1;
+    if (!rc && MODE == GM_DENSITY_EOS) c->stg_kind = c->uniform_state == 1 ? 1 : 0;
     return rc;
 }
 
@@ -950,9 +992,14 @@ static int launch_sweep(SphContext* c) {
 template <int MODE>
 static int launch_df(SphContext* c) {
     if (c->N <= 0) return 0;
-    if (c->opt_gather_impl == 0 || (mode_reads_list<MODE>() && !c->lists_valid)) return launch_simple<MODE>(c, nullptr, c->N);
+    if (c->opt_gather_impl == 0 || (mode_reads_list<MODE>() && !c->lists_valid)) {
+        if (mode_is_df_vdiv<MODE>()) c->k_kind = 0;  // density_adv changes, the walk does not refresh k_j
+        return launch_simple<MODE>(c, nullptr, c->N);
+    }
     int rc = launch_brick_cfg<MODE, Cfg0>(c);
-    if (!rc && mode_writes_list<MODE>()) c->lists_valid = true;
+    if (!rc && mode_writes_list<MODE>()) { c->lists_valid = true; c->stg_kind = 2; c->k_kind = 0; }
+    if (!rc && MODE == GM_DF_DENSITY_CHANGE) c->k_kind = 1;
+    if (!rc && MODE == GM_DF_DENSITY_ADV) c->k_kind = 2;
     return rc;
 }
 
@@ -974,15 +1021,21 @@ int sphk_gather(SphContext* c, int mode) {
         case GM_FORCE_FUSED:
             // one gather per pair when every fluid particle has the same mass (and the density sweep of this step
             // left its stg / gat records): see SPH_OPT_UNIFORM_FLUID
-            if (c->uniform_state == 1 && c->opt_gather_impl == 1 && c->lists_valid && c->sg_valid && c->N > 0)
+            if (c->uniform_state == 1 && c->opt_gather_impl == 1 && c->lists_valid && c->stg_kind == 1 && c->N > 0)
                 return launch_brick<GM_FORCE_FUSED_U>(c);
             return launch_sweep<GM_FORCE_FUSED>(c);
         case GM_DF_DENSITY: return launch_df<GM_DF_DENSITY>(c);
         case GM_DF_FACTOR: return launch_df<GM_DF_FACTOR>(c);
         case GM_DF_DENSITY_CHANGE: return launch_df<GM_DF_DENSITY_CHANGE>(c);
         case GM_DF_DENSITY_ADV: return launch_df<GM_DF_DENSITY_ADV>(c);
-        case GM_DF_DIV_ITER: return launch_df<GM_DF_DIV_ITER>(c);
-        case GM_DF_PRESSURE_ITER: return launch_df<GM_DF_PRESSURE_ITER>(c);
+        // Jacobi sweeps: with the lists, the sign-coded staging records and k_j = b_j * factor_j all current (the
+        // solver loops inside the library keep them so), the neighbour costs one 4-byte gather instead of two records
+        case GM_DF_DIV_ITER:
+            if (c->opt_gather_impl == 1 && c->lists_valid && c->stg_kind == 2 && c->k_kind == 1) return launch_df<GM_DF_DIV_ITER_U>(c);
+            return launch_df<GM_DF_DIV_ITER>(c);
+        case GM_DF_PRESSURE_ITER:
+            if (c->opt_gather_impl == 1 && c->lists_valid && c->stg_kind == 2 && c->k_kind == 2) return launch_df<GM_DF_PRESSURE_ITER_U>(c);
+            return launch_df<GM_DF_PRESSURE_ITER>(c);
         case GM_DF_NONPRESSURE: return launch_df<GM_DF_NONPRESSURE>(c);
     }
     return sph_fail(c, SPH_E_INVALID, "unknown gather mode");

@@ -766,6 +766,7 @@ int sphk_df_scale_factor(SphContext* c, float s) {
     DevView d = sph_view(c);
     hipLaunchKernelGGL(k_df_scale_factor, dim3((c->N + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, s);
     SPH_LAUNCH_CHECK(c);
+    c->k_kind = 0;  // k_j = b_j * factor_j is stale now
     return 0;
 }
 

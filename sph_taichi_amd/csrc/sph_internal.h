@@ -43,13 +43,15 @@ struct DevView {
     float w_zero, w_d;  // W(0), W(d)
     float m_eps;        // DFSPH.py:17
     float m_u;          // the common fluid particle mass (uniform-fluid force path)
-    int write_sg;       // density+EOS finish also writes the stg / gat records of that path
+    int write_sg;       // density finish also writes the stg (/ gat) records of the one-gather sweeps
+    int write_k;        // density-change / -advection finish also writes k_j into kbuf
     float4* xm;
     float4* vf;
     float4* aux;
     float4* eos;
     float4* stg;  // (x, y, z, U): U = m/rho_raw (fluid, > 0) or -m_V (solid)      } uniform-fluid force path:
     float4* gat;  // (vx, vy, vz, p/rho^2) (fluid) or (v, 1 if dynamic else 0) (solid) } staged / gathered records
+    float* kbuf;  // DFSPH: k_j = b_j * dfsph_factor_j (same memory as gat)
     float4* acc;
     int* key;
     int* cell_end;
@@ -105,7 +107,9 @@ struct SphContext {
     size_t stage_bytes;
     bool have_keys, have_prefix, sorted;
     bool lists_valid;   // glist/gcnt describe the CURRENT positions and order (written by a list-writing brick sweep)
-    bool sg_valid;      // stg / gat were written by the density+EOS sweep for the current positions
+    int stg_kind;       // what stg / gat hold for the current positions: 0 nothing, 1 the WCSPH records of
+                        // GM_DENSITY_EOS, 2 the DFSPH record (x, y, z, +m_V fluid / -m_V solid) of GM_DF_DENSITY
+    int k_kind;         // gat-as-float holds k_j = b_j * factor_j: 0 no, 1 b = density_adv, 2 b = density_adv - 1
     bool bricks_valid;  // brick_list/brick_count describe the current order for the target ranges in bricks_key
     int bricks_key[5];  // brick shape id, tgt_lo, tgt_hi, tgt_lo2, tgt_hi2
     double* h_df_err;   // pinned, device-visible: result of compute_density_error
@@ -127,7 +131,7 @@ struct SphContext {
 
 DevView sph_view(const SphContext* c);
 // particle positions / order / flags changed: neighbour lists and the non-empty-brick list are stale
-static inline void sph_invalidate_lists(SphContext* c) { c->lists_valid = false; c->bricks_valid = false; c->sg_valid = false; }
+static inline void sph_invalidate_lists(SphContext* c) { c->lists_valid = false; c->bricks_valid = false; c->stg_kind = 0; c->k_kind = 0; }
 int sph_fail(SphContext* c, int code, const char* what);
 
 #define SPH_HIP(ctx, expr)                                                        \
@@ -181,7 +185,9 @@ enum GatherMode {
     GM_DF_DIV_ITER = 11,       // DFSPH.py:285-321
     GM_DF_PRESSURE_ITER = 12,  // DFSPH.py:356-394
     GM_DF_NONPRESSURE = 13,    // DFSPH.py:49-97
-    GM_FORCE_FUSED_U = 14      // GM_FORCE_FUSED for fluids of one common particle mass: one gather per pair
+    GM_FORCE_FUSED_U = 14,     // GM_FORCE_FUSED for fluids of one common particle mass: one gather per pair
+    GM_DF_DIV_ITER_U = 15,     // GM_DF_DIV_ITER / GM_DF_PRESSURE_ITER with the neighbour's k_j = b_j * factor_j read from a
+    GM_DF_PRESSURE_ITER_U = 16 //   4-byte array (written by the preceding density-change / -advection sweep)
 };
 
 #ifdef __HIPCC__

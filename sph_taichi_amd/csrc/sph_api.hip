@@ -49,6 +49,12 @@ DevView sph_view(const SphContext* c) {
     return d;
 }
 
+struct CellIdx16 { int v[16]; };
+__global__ void k_read_cells(const int* __restrict__ cell_end, CellIdx16 ix, int* __restrict__ out) {
+    const int k = threadIdx.x;
+    if (k < 16 && ix.v[k] >= 0) out[k] = cell_end[ix.v[k]];
+}
+
 extern "C" {
 
 int32_t sph_abi_version(void) { return SPH_ABI_VERSION; }
@@ -134,6 +140,8 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     c->brick_cap = ((params->grid_num[0] + 1) / 2) * ((params->grid_num[1] + 1) / 2) * ((params->grid_num[2] + 3) / 4) + 8;
     rc = rc ? rc : alloc_dev(c, (void**)&c->brick_list, (size_t)c->brick_cap * 4);
     rc = rc ? rc : alloc_dev(c, (void**)&c->brick_count, 16);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->brick_list2, (size_t)c->brick_cap * 4);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->brick_count2, 16);
     const size_t cold = params->cold_capacity > 0 ? (size_t)params->cold_capacity : cap;
     if (cold < cap) { sph_destroy(c); return sph_fail(nullptr, SPH_E_INVALID, "sph_create: cold_capacity < capacity"); }
     c->cold_cap = (int)cold;
@@ -150,9 +158,11 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     if (!rc && hipHostMalloc((void**)&c->h_df_err, sizeof(double), hipHostMallocMapped) != hipSuccess) rc = SPH_E_NOMEM;
     c->stage_bytes = cap * 16 > (size_t)c->G * 4 ? cap * 16 : (size_t)c->G * 4;
     rc = rc ? rc : alloc_dev(c, &c->stage, c->stage_bytes);
-    if (!rc && hipHostMalloc((void**)&c->h_pinned, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess) rc = SPH_E_NOMEM;
+    if (!rc && hipHostMalloc((void**)&c->h_pinned, 16 * sizeof(int), hipHostMallocMapped) != hipSuccess) rc = SPH_E_NOMEM;
     if (!rc && hipEventCreateWithFlags(&c->ev_off, hipEventDisableTiming) != hipSuccess) rc = SPH_E_NOMEM;
     if (!rc && hipEventCreateWithFlags(&c->ev_pack, hipEventDisableTiming) != hipSuccess) rc = SPH_E_NOMEM;
+    if (!rc && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) rc = SPH_E_NOMEM;
+    if (!rc && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) rc = SPH_E_NOMEM;
     if (!rc) rc = sphk_init_pid(c);
     for (int s = 0; s < SPH_MAX_TIMED_STEPS && !rc; ++s)
         for (int k = 0; k < 5 && !rc; ++k)
@@ -179,7 +189,7 @@ int32_t sph_destroy(SphContext* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->xm[0], c->xm[1], c->vf[0], c->vf[1], c->aux[0], c->aux[1], c->key[0], c->key[1], c->eos, c->stg, c->gat, c->acc,
                     c->acc_tmp, c->cell_end, c->rank_off, c->idx_unstable, c->scan_sums, c->x0_cold, c->color_cold,
-                    c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->rigid_part, c->rigid_R, c->df_err, c->df_part, c->stage, c->glist, c->gcnt, c->brick_list, c->brick_count};
+                    c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->rigid_part, c->rigid_R, c->df_err, c->df_part, c->stage, c->glist, c->gcnt, c->brick_list, c->brick_count, c->brick_list2, c->brick_count2};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < SPH_MAX_TIMED_STEPS; ++s)
         for (int k = 0; k < 5; ++k) if (c->ev[s][k]) (void)hipEventDestroy(c->ev[s][k]);
@@ -187,6 +197,8 @@ int32_t sph_destroy(SphContext* c) {
     if (c->h_df_err) (void)hipHostFree(c->h_df_err);
     if (c->ev_off) (void)hipEventDestroy(c->ev_off);
     if (c->ev_pack) (void)hipEventDestroy(c->ev_pack);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->side) (void)hipStreamDestroy(c->side);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -580,12 +592,20 @@ int32_t sph_layer_offsets_begin(SphContext* c, const int32_t* layers, int32_t n)
     if (!c->have_prefix) return sph_fail(c, SPH_E_STATE, "sph_layer_offsets_begin needs the prefix sum");
     const int per_layer = c->p.grid_num[1] * c->p.grid_num[2];
     c->off_zero_mask = 0;
+    CellIdx16 ix;
+    for (int k = 0; k < 16; ++k) ix.v[k] = -1;
     for (int k = 0; k < n; ++k) {
         const int L = layers[k];
         if (L < 0 || L > c->p.grid_num[0]) return sph_fail(c, SPH_E_INVALID, "layer out of range");
         if (L == 0) { c->off_zero_mask |= 1 << k; continue; }
-        SPH_HIP(c, hipMemcpyAsync(&c->h_pinned[k], c->cell_end + (size_t)L * per_layer - 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        ix.v[k] = L * per_layer - 1;
     }
+    // one tiny kernel writes all offsets straight into mapped pinned memory (n separate device-to-host copies
+    // used to sit on the stream between the sort and the density sweep)
+    int* dev_out = nullptr;
+    SPH_HIP(c, hipHostGetDevicePointer((void**)&dev_out, c->h_pinned, 0));
+    hipLaunchKernelGGL(k_read_cells, dim3(1), dim3(64), 0, c->stream, c->cell_end, ix, dev_out);
+    SPH_LAUNCH_CHECK(c);
     SPH_HIP(c, hipEventRecord(c->ev_off, c->stream));
     return 0;
 }
@@ -711,15 +731,22 @@ int32_t sph_slab_forces(SphContext* c, int32_t bl_lo, int32_t bl_hi, int32_t br_
     br_hi = br_hi > f_hi ? f_hi : br_hi; br_lo = br_lo < bl_hi ? bl_hi : br_lo;
     if (bl_hi < bl_lo) bl_hi = bl_lo;
     if (br_lo > br_hi) br_lo = br_hi;
-    // boundary sets (incl. the ghost-side strips that exist when dynamic solids are force targets): ONE launch
+    // Boundary sets (incl. the ghost-side strips that exist when dynamic solids are force targets) in ONE launch, then
+    // the two packers -- on the side stream, so the big interior sweep does not queue behind that small launch (a few
+    // hundred workgroups cannot fill 256 CUs) but runs beside it.  Both sweeps write disjoint targets' accelerations.
+    SPH_HIP(c, hipEventRecord(c->ev_fork, c->stream));
+    SPH_HIP(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    c->use_side = true;
     rc = sphk_gather_layers(c, GM_FORCE_FUSED, f_lo, bl_hi, br_lo, f_hi);
     rc = rc ? rc : sphk_pack_advected(c, firstL, nL, dstL);
     rc = rc ? rc : sphk_pack_advected(c, firstR, nR, dstR);
+    c->use_side = false;
     if (rc) return rc;
-    SPH_HIP(c, hipEventRecord(c->ev_pack, c->stream));
+    SPH_HIP(c, hipEventRecord(c->ev_pack, c->side));
     rc = sphk_gather_layers(c, GM_FORCE_FUSED, bl_hi, br_lo, 0, 0);  // interior: overlaps with the exchange
-    rc = rc ? rc : sphk_advect(c, true);
-    return rc;
+    if (rc) return rc;
+    SPH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pack, 0));  // the packers read what the advect overwrites
+    return sphk_advect(c, true);
 }
 
 int32_t sph_slab_density(SphContext* c) {

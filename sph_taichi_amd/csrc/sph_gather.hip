@@ -943,16 +943,20 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
     // the list of non-empty bricks depends only on the order and the target layers: every sweep of a step that
     // shares them (density + force; all ~30 sweeps of a DFSPH step) reuses it
     const int key[5] = {CFG::BX * 100 + CFG::BY * 10 + CFG::BZ, d.tgt_lo, d.tgt_hi, d.tgt_lo2, d.tgt_hi2};
-    if (!c->bricks_valid || memcmp(key, c->bricks_key, sizeof(key)) != 0) {
-        SPH_HIP(c, hipMemsetAsync(c->brick_count, 0, sizeof(int), c->stream));
-        hipLaunchKernelGGL((k_brick_list<CFG>), dim3((nbricks + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, nbx, nby, nbz,
-                           c->brick_list, c->brick_count);
+    hipStream_t st = sph_stream(c);
+    int* blist = c->use_side ? c->brick_list2 : c->brick_list;
+    int* bcount = c->use_side ? c->brick_count2 : c->brick_count;
+    if (c->use_side || !c->bricks_valid || memcmp(key, c->bricks_key, sizeof(key)) != 0) {
+        SPH_HIP(c, hipMemsetAsync(bcount, 0, sizeof(int), st));
+        hipLaunchKernelGGL((k_brick_list<CFG>), dim3((nbricks + TPB - 1) / TPB), dim3(TPB), 0, st, d, nbx, nby, nbz, blist, bcount);
         SPH_LAUNCH_CHECK(c);
-        memcpy(c->bricks_key, key, sizeof(key));
-        c->bricks_valid = true;
+        if (!c->use_side) {  // (the side stream's list is private to that launch and never cached)
+            memcpy(c->bricks_key, key, sizeof(key));
+            c->bricks_valid = true;
+        }
     }
-    hipLaunchKernelGGL((k_gather_brick<MODE, CFG>), dim3(grid), dim3(TPB), bytes, c->stream, d, nby, nbz, c->brick_list,
-                       c->brick_count, c->glist, c->gcnt, c->cap);
+    hipLaunchKernelGGL((k_gather_brick<MODE, CFG>), dim3(grid), dim3(TPB), bytes, st, d, nby, nbz, blist, bcount, c->glist,
+                       c->gcnt, c->cap);
     SPH_LAUNCH_CHECK(c);
     return 0;
 }

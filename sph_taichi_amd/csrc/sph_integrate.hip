@@ -617,7 +617,7 @@ int sphk_advect(SphContext* c, bool fused_fluid_walls) {
 int sphk_pack_advected(SphContext* c, int first, int count, void* dst) {
     if (count <= 0) return 0;
     DevView d = sph_view(c);
-    hipLaunchKernelGGL(k_pack_advected, dim3((count + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, wall_hi(c), first, count,
+    hipLaunchKernelGGL(k_pack_advected, dim3((count + TPB - 1) / TPB), dim3(TPB), 0, sph_stream(c), d, wall_hi(c), first, count,
                        (float4*)dst);
     SPH_LAUNCH_CHECK(c);
     return 0;

@@ -72,6 +72,11 @@ struct SphContext {
     int* h_pinned;       // 16 ints of pinned host memory for sph_layer_offsets_begin/_end
     hipEvent_t ev_off;   // recorded behind those copies
     hipEvent_t ev_pack;  // recorded behind the halo packers of sph_slab_forces
+    hipEvent_t ev_fork;  // main stream -> side stream hand-off in sph_slab_forces
+    hipStream_t side;    // slab mode: boundary force sweep + halo packers run here, concurrently with the interior sweep
+    bool use_side;       // launchers enqueue on `side` (with their own brick list) while this is set
+    int* brick_list2;    // [brick_cap] brick list of launches on the side stream
+    int* brick_count2;
     int off_zero_mask;   // which of the pending offsets are layer 0 (no copy needed)
     int tgt_layers[4];  // density lo/hi, force lo/hi (slab mode); default 0..nx
     int in_off;  // first live record of the current set (non-zero only between sph_select_range and the next sort)
@@ -130,6 +135,7 @@ struct SphContext {
 };
 
 DevView sph_view(const SphContext* c);
+static inline hipStream_t sph_stream(const SphContext* c) { return c->use_side ? c->side : c->stream; }
 // particle positions / order / flags changed: neighbour lists and the non-empty-brick list are stale
 static inline void sph_invalidate_lists(SphContext* c) { c->lists_valid = false; c->bricks_valid = false; c->stg_kind = 0; c->k_kind = 0; }
 int sph_fail(SphContext* c, int code, const char* what);

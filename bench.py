@@ -246,6 +246,9 @@ def main():
         "k_gather_brick<GM_DENSITY_EOS>": (32.0 * N + 4.0 * G, neigh_ms),
         "k_gather_brick<GM_FORCE_FUSED>": (60.0 * N + 4.0 * G, force_ms),
     }
+    one_gather = ps.get_option(_lib.OPT_UNIFORM_FLUID_STATE) == 1 and args.fused == 1
+    if one_gather:      # the force sweep that actually ran (SPH_OPT_UNIFORM_FLUID: all fluid masses equal)
+        kernels["k_gather_brick<GM_FORCE_FUSED_U>"] = kernels.pop("k_gather_brick<GM_FORCE_FUSED>")
     if not args.gather_impl:
         kernels = {k_.replace("brick", "simple"): v for k_, v in kernels.items()}
     dominant = max(kernels, key=lambda k_: kernels[k_][1])

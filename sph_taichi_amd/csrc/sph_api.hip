@@ -207,13 +207,13 @@ int32_t sph_destroy(SphContext* c) {
 int32_t sph_set_option(SphContext* c, int32_t option, int32_t value) {
     if (!c) return SPH_E_INVALID;
     switch (option) {
-        case SPH_OPT_GATHER_IMPL: if (value < 0 || value > 1) return sph_fail(c, SPH_E_INVALID, "gather impl must be 0 or 1"); c->opt_gather_impl = value; return 0;
+        case SPH_OPT_GATHER_IMPL: if (value < 0 || value > 1) return sph_fail(c, SPH_E_INVALID, "gather impl must be 0 or 1"); c->opt_gather_impl = value; c->uniform_state = -1; return 0;
         case SPH_OPT_TIMING: c->opt_timing = value ? 1 : 0; return 0;
         case SPH_OPT_FUSED_STEP: c->opt_fused = value ? 1 : 0; return 0;
         case SPH_OPT_BRICK_SHAPE: if (value < 0 || value > 3) return sph_fail(c, SPH_E_INVALID, "brick shape must be 0..3"); c->opt_brick_shape = value; return 0;
-        case SPH_OPT_NO_DYNAMIC_SOLIDS: c->opt_no_dynamic = value ? 1 : 0; c->n_dyn_host = -1; return 0;
+        case SPH_OPT_NO_DYNAMIC_SOLIDS: c->opt_no_dynamic = value ? 1 : 0; c->n_dyn_host = -1; c->uniform_state = -1; return 0;
         case SPH_OPT_DEBUG_ABLATE: c->opt_ablate = value; return 0;
-        case SPH_OPT_SLAB_DROP_OUTSIDE: c->opt_drop_outside = value ? 1 : 0; return 0;
+        case SPH_OPT_SLAB_DROP_OUTSIDE: c->opt_drop_outside = value ? 1 : 0; c->uniform_state = -1; return 0;
         case SPH_OPT_UNIFORM_FLUID: if (value < -1 || value > 1) return sph_fail(c, SPH_E_INVALID, "uniform-fluid option must be -1, 0 or 1"); c->opt_uniform = value; c->uniform_state = -1; return 0;
     }
     return sph_fail(c, SPH_E_INVALID, "unknown option");

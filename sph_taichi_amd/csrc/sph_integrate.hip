@@ -59,14 +59,15 @@ __global__ __launch_bounds__(TPB) void k_advect(DevView d, WallHi hi) {
 // out[0] = min, out[1] = max of the mass bit patterns (positive floats order like unsigned ints), out[2] = number of
 // fluid particles whose m_V differs from m_V0, out[3] = number of fluid particles.
 __global__ __launch_bounds__(TPB) void k_check_uniform(DevView d, unsigned* __restrict__ out) {
-    const int i = blockIdx.x * TPB + threadIdx.x;
     unsigned lo = 0xFFFFFFFFu, hi = 0u;
     int bad = 0, nf = 0;
-    if (i < d.N && sph_is_fluid(__float_as_int(d.vf[i].w))) {
-        lo = hi = __float_as_uint(d.aux[i].x);
-        bad = __float_as_uint(d.xm[i].w) != __float_as_uint(d.m_V0) ? 1 : 0;
-        nf = 1;
-    }
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < d.N; i += gridDim.x * TPB)  // few blocks: few same-address atomics
+        if (sph_is_fluid(__float_as_int(d.vf[i].w))) {
+            const unsigned mb = __float_as_uint(d.aux[i].x);
+            lo = min(lo, mb); hi = max(hi, mb);
+            bad += __float_as_uint(d.xm[i].w) != __float_as_uint(d.m_V0) ? 1 : 0;
+            nf += 1;
+        }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         lo = min(lo, (unsigned)__shfl_down((int)lo, off, 64));
@@ -798,7 +799,8 @@ int sphk_check_uniform_fluid(SphContext* c) {
     const unsigned init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
     unsigned h[4];
     SPH_HIP(c, hipMemcpyAsync(out, init, sizeof(init), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_check_uniform, dim3((c->N + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, out);
+    const int nb_chk = (c->N + TPB - 1) / TPB < 512 ? (c->N + TPB - 1) / TPB : 512;
+    hipLaunchKernelGGL(k_check_uniform, dim3(nb_chk), dim3(TPB), 0, c->stream, d, out);
     SPH_LAUNCH_CHECK(c);
     SPH_HIP(c, hipMemcpyAsync(h, out, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     SPH_HIP(c, hipStreamSynchronize(c->stream));

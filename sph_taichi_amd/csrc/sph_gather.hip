@@ -533,7 +533,8 @@ __global__ __launch_bounds__(TPB) void k_gather_bvol_split(DevView d, const int*
 // ---------------------------------------------------------------------------
 // LDS holds one float4 per shell record (see the carve in BrickCfg): for a
 // filtering sweep (-2x', -2y', -2z', |x'|^2) in shell-local coordinates plus a
-// separate m_V array, for a list-reading sweep the record (x, y, z, m_V) itself.
+// separate m_V array, for a list-reading sweep the record (x, y, z, m_V) itself (the one-gather sweeps
+// GM_FORCE_FUSED_U / GM_DF_*_ITER_U stage the `stg` record instead, whose 4th word also tells fluid from solid).
 // List entries are u16: (shell column << 11) | LDS slot, so CAP <= 2048 and
 // NCOL <= 32; the global index of a slot is slot + sColG[col] (sColG = global start - LDS start of the column).
 // In the fused step the density sweep writes each target's list to HBM

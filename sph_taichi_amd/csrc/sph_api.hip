@@ -701,17 +701,28 @@ int32_t sph_slab_pack(SphContext* c, int32_t firstL, int32_t nL, void* dstL, int
 int32_t sph_slab_advance(SphContext* c, int32_t keep_first, int32_t keep_count, const void* srcL, int32_t nL,
                          const void* srcR, int32_t nR, const int32_t* layers, int32_t n_layers, int32_t do_sweeps) {
     ENTER(c);
+    // SPH_OPT_TIMING in slab mode: the five events of one step are split over this call (sort, density) and the
+    // following sph_slab_forces (force, advect); the halo exchange itself is host-side and not on this stream
+    hipEvent_t* ev = nullptr;
+    c->slab_ev_open = false;
+    if (c->opt_timing && do_sweeps == 2) {
+        if (c->ev_used == SPH_MAX_TIMED_STEPS) { int rh = harvest_events(c); if (rh) return rh; }
+        ev = c->ev[c->ev_used];
+        SPH_HIP(c, hipEventRecord(ev[0], c->stream));
+    }
     int rc = sph_select_range(c, keep_first, keep_count);
     rc = rc ? rc : sph_append_records(c, srcL, nL);
     rc = rc ? rc : sph_append_records(c, srcR, nR);
     rc = rc ? rc : sph_sort(c);
     rc = rc ? rc : sph_layer_offsets_begin(c, layers, n_layers);
+    if (!rc && ev) SPH_HIP(c, hipEventRecord(ev[1], c->stream));
     if (!rc && do_sweeps == 1) rc = sph_sweeps(c);
     if (!rc && do_sweeps == 2) {  // boundary volume + density only; sph_slab_forces does the rest
         rc = refresh_dyn(c);
         rc = rc ? rc : uniform_fluid(c);
         if (!rc && c->n_dyn_host > 0) rc = sphk_gather(c, GM_BVOL_DYNAMIC);
         rc = rc ? rc : sphk_gather(c, GM_DENSITY_EOS);
+        if (!rc && ev) { SPH_HIP(c, hipEventRecord(ev[2], c->stream)); c->slab_ev_open = true; }
     }
     return rc;
 }
@@ -746,7 +757,11 @@ int32_t sph_slab_forces(SphContext* c, int32_t bl_lo, int32_t bl_hi, int32_t br_
     rc = sphk_gather_layers(c, GM_FORCE_FUSED, bl_hi, br_lo, 0, 0);  // interior: overlaps with the exchange
     if (rc) return rc;
     SPH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pack, 0));  // the packers read what the advect overwrites
-    return sphk_advect(c, true);
+    hipEvent_t* ev = c->slab_ev_open ? c->ev[c->ev_used] : nullptr;
+    if (ev) SPH_HIP(c, hipEventRecord(ev[3], c->stream));  // force = interior sweep (+ the wait for the side stream)
+    rc = sphk_advect(c, true);
+    if (!rc && ev) { SPH_HIP(c, hipEventRecord(ev[4], c->stream)); c->ev_used++; c->slab_ev_open = false; }
+    return rc;
 }
 
 int32_t sph_slab_density(SphContext* c) {

@@ -130,6 +130,7 @@ struct SphContext {
     // timing
     hipEvent_t ev[SPH_MAX_TIMED_STEPS][5];
     int ev_used;
+    bool slab_ev_open;  // slab mode: events [0..2] of ev[ev_used] are recorded, [3..4] follow in sph_slab_forces
     SphTimings tm;
     char err[512];
 };

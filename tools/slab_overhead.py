@@ -21,4 +21,9 @@ s = SlabSolver(sd, 0, 1, device=0)
 s.attach(NoTransport()); s.initialize(); s.step(10); s.ps.sync()
 t0 = time.perf_counter(); s.step(100); s.ps.sync(); t1 = time.perf_counter()
 print(f"SlabSolver world=1 (no msg): {(t1 - t0) * 10:.3f} ms/step")
+s.ps.set_option(_lib.OPT_TIMING, 1); s.ps._call("sph_reset_timings")
+t0 = time.perf_counter(); s.step(100); s.ps.sync(); t1 = time.perf_counter()
+tm = _lib.SphTimings(); s.ps._call("sph_get_timings", tm)
+print(f"  with SPH_OPT_TIMING      : {(t1 - t0) * 10:.3f} ms/step; events: sort {tm.sort_ms/tm.steps:.3f} density {tm.neighbour_ms/tm.steps:.3f} "
+      f"force {tm.force_ms/tm.steps:.3f} advect {tm.integrate_ms/tm.steps:.3f}; host {s.host_ms}")
 s.close()

@@ -745,15 +745,18 @@ int32_t sph_slab_forces(SphContext* c, int32_t bl_lo, int32_t bl_hi, int32_t br_
     // Boundary sets (incl. the ghost-side strips that exist when dynamic solids are force targets) in ONE launch, then
     // the two packers -- on the side stream, so the big interior sweep does not queue behind that small launch (a few
     // hundred workgroups cannot fill 256 CUs) but runs beside it.  Both sweeps write disjoint targets' accelerations.
-    SPH_HIP(c, hipEventRecord(c->ev_fork, c->stream));
-    SPH_HIP(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
-    c->use_side = true;
+    static const bool no_side = getenv("SPH_NO_SIDE_STREAM") != nullptr;  // debugging aid: everything on one stream
+    if (!no_side) {
+        SPH_HIP(c, hipEventRecord(c->ev_fork, c->stream));
+        SPH_HIP(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        c->use_side = true;
+    }
     rc = sphk_gather_layers(c, GM_FORCE_FUSED, f_lo, bl_hi, br_lo, f_hi);
     rc = rc ? rc : sphk_pack_advected(c, firstL, nL, dstL);
     rc = rc ? rc : sphk_pack_advected(c, firstR, nR, dstR);
     c->use_side = false;
     if (rc) return rc;
-    SPH_HIP(c, hipEventRecord(c->ev_pack, c->side));
+    SPH_HIP(c, hipEventRecord(c->ev_pack, no_side ? c->stream : c->side));
     rc = sphk_gather_layers(c, GM_FORCE_FUSED, bl_hi, br_lo, 0, 0);  // interior: overlaps with the exchange
     if (rc) return rc;
     SPH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pack, 0));  // the packers read what the advect overwrites

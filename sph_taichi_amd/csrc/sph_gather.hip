@@ -345,8 +345,12 @@ __device__ __forceinline__ void target_finish(const DevView& d, Target& t, int i
         if (gathered) {
             const float rho_raw = (t.self_in_sum ? t.s0 : t.mV * d.w_zero + t.s0) * d.rho0;  // WCSPH.py:39-43
             const float rho = fmaxf(rho_raw, d.rho0);                 // WCSPH.py:75
-            const float p = d.stiffness * (powf(rho / d.rho0, d.exponent) - 1.0f);  // WCSPH.py:76
-            e = make_float4(p / (rho * rho), aux.x / rho_raw, aux.x, rho);
+            // WCSPH.py:76 ti.pow(rho / rho0, exponent) as exp2(exponent * log2(x)) on the hardware transcendentals
+            // (~1e-6 relative on p; exactly 0 at rho = rho0, where most of a resting fluid sits after the clamp) and
+            // reciprocals instead of IEEE divisions: libm powf + three divides were ~130 instructions per particle
+            const float xr = rho * sph_rcp(d.rho0);
+            const float p = d.stiffness * (__builtin_amdgcn_exp2f(d.exponent * __builtin_amdgcn_logf(xr)) - 1.0f);
+            e = make_float4(p * sph_rcp(rho * rho), aux.x * sph_rcp(rho_raw), aux.x, rho);
             aux.y = rho; aux.z = p;
             d.aux[i] = aux;
         } else {

@@ -130,7 +130,9 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     rc = rc ? rc : alloc_dev(c, (void**)&c->gat, cap * 16);
     rc = rc ? rc : alloc_dev(c, (void**)&c->acc, cap * 16);
     rc = rc ? rc : alloc_dev(c, (void**)&c->acc_tmp, cap * 16);
-    rc = rc ? rc : alloc_dev(c, (void**)&c->cell_end, (size_t)c->scan_blocks * SCAN_TILE * 4);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->cell_buf[0], (size_t)c->scan_blocks * SCAN_TILE * 4);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->cell_buf[1], (size_t)c->scan_blocks * SCAN_TILE * 4);
+    if (!rc) { c->cell_cur = 0; c->cell_end = c->cell_buf[0]; c->next_cells_zero = false; }
     rc = rc ? rc : alloc_dev(c, (void**)&c->rank_off, cap * 4);
     rc = rc ? rc : alloc_dev(c, (void**)&c->idx_unstable, cap * 4);
     rc = rc ? rc : alloc_dev(c, (void**)&c->scan_sums, (size_t)(c->scan_blocks + 1) * 4);
@@ -188,7 +190,7 @@ int32_t sph_destroy(SphContext* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->xm[0], c->xm[1], c->vf[0], c->vf[1], c->aux[0], c->aux[1], c->key[0], c->key[1], c->eos, c->stg, c->gat, c->acc,
-                    c->acc_tmp, c->cell_end, c->rank_off, c->idx_unstable, c->scan_sums, c->x0_cold, c->color_cold,
+                    c->acc_tmp, c->cell_buf[0], c->cell_buf[1], c->rank_off, c->idx_unstable, c->scan_sums, c->x0_cold, c->color_cold,
                     c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->rigid_part, c->rigid_R, c->df_err, c->df_part, c->stage, c->glist, c->gcnt, c->brick_list, c->brick_count, c->brick_list2, c->brick_count2};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < SPH_MAX_TIMED_STEPS; ++s)

@@ -952,7 +952,8 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
     int* blist = c->use_side ? c->brick_list2 : c->brick_list;
     int* bcount = c->use_side ? c->brick_count2 : c->brick_count;
     if (c->use_side || !c->bricks_valid || memcmp(key, c->bricks_key, sizeof(key)) != 0) {
-        SPH_HIP(c, hipMemsetAsync(bcount, 0, sizeof(int), st));
+        if (c->use_side || !c->brick_count_zero) SPH_HIP(c, hipMemsetAsync(bcount, 0, sizeof(int), st));
+        if (!c->use_side) c->brick_count_zero = false;
         hipLaunchKernelGGL((k_brick_list<CFG>), dim3((nbricks + TPB - 1) / TPB), dim3(TPB), 0, st, d, nbx, nby, nbz, blist, bcount);
         SPH_LAUNCH_CHECK(c);
         if (!c->use_side) {  // (the side stream's list is private to that launch and never cached)

@@ -92,6 +92,7 @@ struct SphContext {
     int* cell_end;     // [G+1] the CURRENT cell array (one of cell_buf[])
     int* cell_buf[2];  // two cell arrays: while one serves the sweeps, the scatter zeroes the other for the next histogram
     int cell_cur;
+    bool brick_count_zero;  // brick_count was zeroed by the scatter (the first brick-list build of a step needs no memset)
     bool next_cells_zero;  // cell_buf[cell_cur ^ 1] is all zero (no memset needed before the next histogram)
     int* rank_off;     // [cap] arbitrary intra-cell offset from the histogram atomics
     int* idx_unstable; // [cap]

@@ -134,8 +134,9 @@ __global__ __launch_bounds__(TPB) void k_scan_apply(int4* __restrict__ data, con
 }
 
 __global__ __launch_bounds__(TPB) void k_unstable_place(DevView d, const int* __restrict__ rank_off,
-                                                        int* __restrict__ idx_unstable) {
+                                                        int* __restrict__ idx_unstable, int* __restrict__ dyn_count) {
     const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i == 0) *dyn_count = 0;  // counted by the scatter that follows (saves a memset launch)
     if (i >= d.N) return;
     const int c = d.key[i];
     const int b = c > 0 ? d.cell_end[c - 1] : 0;  // particle_system.py:327-329 base_offset
@@ -148,8 +149,9 @@ __global__ __launch_bounds__(TPB) void k_stable_scatter(DevView d, const int* __
                                                         float4* __restrict__ aux_out, int* __restrict__ key_out,
                                                         float4* __restrict__ acc_out, int* __restrict__ dyn_list,
                                                         int* __restrict__ dyn_count, int4* __restrict__ zero_dst,
-                                                        int zero_n4) {
+                                                        int zero_n4, int* __restrict__ brick_count) {
     const int s = blockIdx.x * TPB + threadIdx.x;
+    if (s == 0) *brick_count = 0;  // for the first brick-list build on the new order
     // the OTHER cell array (the previous step's, dead by now) is zeroed here for the next histogram: 2 MB of stores in
     // a 180 MB kernel instead of a memset launch of its own (~10 us per step)
     for (int z = s; z < zero_n4; z += gridDim.x * TPB) zero_dst[z] = make_int4(0, 0, 0, 0);
@@ -211,17 +213,17 @@ int sphk_sort_scatter(SphContext* c, bool sort_acc) {
     const int o = c->cur ^ 1;
     int4* zero_dst = reinterpret_cast<int4*>(c->cell_buf[c->cell_cur ^ 1]);
     const int zero_n4 = c->scan_blocks * SCAN_TILE / 4;
-    SPH_HIP(c, hipMemsetAsync(c->dyn_count, 0, sizeof(int), c->stream));
-    hipLaunchKernelGGL(k_unstable_place, dim3(nb), dim3(TPB), 0, c->stream, d, c->rank_off, c->idx_unstable);
+    hipLaunchKernelGGL(k_unstable_place, dim3(nb), dim3(TPB), 0, c->stream, d, c->rank_off, c->idx_unstable, c->dyn_count);
     SPH_LAUNCH_CHECK(c);
     if (sort_acc)
         hipLaunchKernelGGL(k_stable_scatter<true>, dim3(nb), dim3(TPB), 0, c->stream, d, c->idx_unstable, c->xm[o],
-                           c->vf[o], c->aux[o], c->key[o], c->acc_tmp, c->dyn_list, c->dyn_count, zero_dst, zero_n4);
+                           c->vf[o], c->aux[o], c->key[o], c->acc_tmp, c->dyn_list, c->dyn_count, zero_dst, zero_n4, c->brick_count);
     else
         hipLaunchKernelGGL(k_stable_scatter<false>, dim3(nb), dim3(TPB), 0, c->stream, d, c->idx_unstable, c->xm[o],
-                           c->vf[o], c->aux[o], c->key[o], c->acc_tmp, c->dyn_list, c->dyn_count, zero_dst, zero_n4);
+                           c->vf[o], c->aux[o], c->key[o], c->acc_tmp, c->dyn_list, c->dyn_count, zero_dst, zero_n4, c->brick_count);
     SPH_LAUNCH_CHECK(c);
     c->next_cells_zero = true;
+    c->brick_count_zero = true;
     c->cur = o;
     sph_invalidate_lists(c);
     if (sort_acc) {

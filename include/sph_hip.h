@@ -122,7 +122,11 @@ enum SphOption {
                                   -1 (default) = check on the device whenever m / m_V / material were uploaded or the
                                   particle set changed, and use it when it holds; 0 = never; 1 = check once, then the
                                   caller vouches for later arrivals (slab ranks: migrating particles of the same scene) */,
-    SPH_OPT_UNIFORM_FLUID_STATE = 8 /* read-only (sph_get_option): -1 not decided yet, 0 general sweep, 1 one-gather sweep */
+    SPH_OPT_UNIFORM_FLUID_STATE = 8 /* read-only (sph_get_option): -1 not decided yet, 0 general sweep, 1 one-gather sweep */,
+    SPH_OPT_SORT_BY_PID = 9    /* 1 = inside a cell, order by persistent id instead of by previous index.  The reference
+                                  order (previous index) is kept on a single GPU; slab ranks running DFSPH need an order
+                                  that the owner of a boundary band and the neighbour holding it as ghosts agree on, so
+                                  that ghost velocities can be refreshed record for record */
 };
 
 /* ms accumulated by sph_step since the last sph_reset_timings (HIP events on
@@ -297,6 +301,12 @@ int32_t sph_dfsph_advect(SphContext* ctx);                         /* DFSPH.py:1
 /* n_steps x SPHBase.step() with DFSPHSolver.substep (sph_base.py:263-271, DFSPH.py:400-408).  Phase timings:
  * neighbour = boundary volume + density + factor, force = both solvers + non-pressure forces + predict_velocity. */
 int32_t sph_dfsph_step(SphContext* ctx, int32_t n_steps, const int32_t* dynamic_ids, int32_t n_dynamic);
+/* DFSPH across slabs: a rank's share of compute_density_error over its OWNED records [first, first+count) (f64, to be
+ * all-reduced; synchronises), and the velocity records (v + flags, 16 B each) of a contiguous range copied to
+ * (to_context = 0) or from (1) a caller-owned device buffer -- each Jacobi sweep is followed by a refresh of the ghost
+ * layers' velocities from their owners. */
+int32_t sph_dfsph_compute_density_error_range(SphContext* ctx, float offset, int32_t first, int32_t count, double* out);
+int32_t sph_copy_velocity_records(SphContext* ctx, int32_t first, int32_t count, void* device_buf, int32_t to_context);
 
 #ifdef __cplusplus
 }

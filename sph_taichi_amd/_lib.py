@@ -50,7 +50,7 @@ F_OBJECT_ID, F_X, F_X_0, F_V, F_ACCELERATION, F_M_V, F_M, F_DENSITY, F_PRESSURE,
     F_IS_DYNAMIC, F_GRID_IDS, F_GRID_PARTICLES_NUM, F_PID, F_RIGID_REST_CM, F_DFSPH_FACTOR, F_DENSITY_ADV = range(18)
 # enum SphOption
 OPT_GATHER_IMPL, OPT_TIMING, OPT_FUSED_STEP, OPT_BRICK_SHAPE, OPT_NO_DYNAMIC_SOLIDS, OPT_DEBUG_ABLATE, \
-    OPT_SLAB_DROP_OUTSIDE, OPT_UNIFORM_FLUID, OPT_UNIFORM_FLUID_STATE = range(9)
+    OPT_SLAB_DROP_OUTSIDE, OPT_UNIFORM_FLUID, OPT_UNIFORM_FLUID_STATE, OPT_SORT_BY_PID = range(10)
 
 ABI_VERSION = 2
 
@@ -123,6 +123,8 @@ SYMBOLS = [
     ("sph_dfsph_predict_velocity", C.c_int32, [_ctx]),
     ("sph_dfsph_advect", C.c_int32, [_ctx]),
     ("sph_dfsph_step", C.c_int32, [_ctx, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
+    ("sph_dfsph_compute_density_error_range", C.c_int32, [_ctx, C.c_float, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
+    ("sph_copy_velocity_records", C.c_int32, [_ctx, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
 ]
 
 _LIB = None

@@ -24,6 +24,7 @@ DevView sph_view(const SphContext* c) {
     d.tgt_lo = 0; d.tgt_hi = p.grid_num[0]; d.tgt_lo2 = d.tgt_hi2 = 0;
     d.ablate = c->opt_ablate;
     d.drop_outside = c->opt_drop_outside;
+    d.sort_by_pid = c->opt_sort_by_pid;
     d.ox = p.cell_origin[0]; d.oy = p.cell_origin[1]; d.oz = p.cell_origin[2];
     d.grid_size = p.grid_size; d.h = p.support_radius; d.inv_h = 1.0f / p.support_radius;
     d.d2 = p.particle_diameter * p.particle_diameter;  // WCSPH.py:96
@@ -216,6 +217,7 @@ int32_t sph_set_option(SphContext* c, int32_t option, int32_t value) {
         case SPH_OPT_NO_DYNAMIC_SOLIDS: c->opt_no_dynamic = value ? 1 : 0; c->n_dyn_host = -1; c->uniform_state = -1; return 0;
         case SPH_OPT_DEBUG_ABLATE: c->opt_ablate = value; return 0;
         case SPH_OPT_SLAB_DROP_OUTSIDE: c->opt_drop_outside = value ? 1 : 0; c->uniform_state = -1; return 0;
+        case SPH_OPT_SORT_BY_PID: c->opt_sort_by_pid = value ? 1 : 0; return 0;
         case SPH_OPT_UNIFORM_FLUID: if (value < -1 || value > 1) return sph_fail(c, SPH_E_INVALID, "uniform-fluid option must be -1, 0 or 1"); c->opt_uniform = value; c->uniform_state = -1; return 0;
     }
     return sph_fail(c, SPH_E_INVALID, "unknown option");
@@ -232,6 +234,7 @@ int32_t sph_get_option(const SphContext* c, int32_t option, int32_t* value) {
         case SPH_OPT_DEBUG_ABLATE: *value = c->opt_ablate; return 0;
         case SPH_OPT_SLAB_DROP_OUTSIDE: *value = c->opt_drop_outside; return 0;
         case SPH_OPT_UNIFORM_FLUID: *value = c->opt_uniform; return 0;
+        case SPH_OPT_SORT_BY_PID: *value = c->opt_sort_by_pid; return 0;
         case SPH_OPT_UNIFORM_FLUID_STATE: *value = c->uniform_state; return 0;
     }
     return SPH_E_INVALID;
@@ -849,6 +852,23 @@ int32_t sph_dfsph_compute_density_error(SphContext* c, float offset, float* out)
     ENTER(c);
     if (!out) return SPH_E_INVALID;
     return sphk_df_density_error(c, offset, out);
+}
+
+int32_t sph_dfsph_compute_density_error_range(SphContext* c, float offset, int32_t first, int32_t count, double* out) {
+    ENTER(c);
+    if (!out || first < 0 || count < 0 || first + count > c->N) return sph_fail(c, SPH_E_INVALID, "sph_dfsph_compute_density_error_range: bad range");
+    return sphk_df_density_error_range(c, offset, first, count, out);
+}
+
+int32_t sph_copy_velocity_records(SphContext* c, int32_t first, int32_t count, void* device_buf, int32_t to_context) {
+    ENTER(c);
+    if (first < 0 || count < 0 || first + count > c->N || (count > 0 && !device_buf))
+        return sph_fail(c, SPH_E_INVALID, "sph_copy_velocity_records: bad range");
+    if (count == 0) return 0;
+    float4* vf = c->vf[c->cur] + (size_t)c->in_off + first;
+    if (to_context) SPH_HIP(c, hipMemcpyAsync(vf, device_buf, (size_t)count * 16, hipMemcpyDeviceToDevice, c->stream));
+    else SPH_HIP(c, hipMemcpyAsync(device_buf, vf, (size_t)count * 16, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
 }
 
 int32_t sph_dfsph_multiply_time_step(SphContext* c, float time_step) {

@@ -128,10 +128,11 @@ __global__ __launch_bounds__(TPB) void k_df_scale_factor(DevView d, float s) {
 // DFSPH.py:224-230 compute_density_error: sum over fluid of density_0 * density_adv - offset.  Two stages, f64
 // partials in a fixed order (the reference's f32 reduction order is scheduling-dependent anyway); the total lands
 // in pinned host memory, so the host only waits for the stream.
-__global__ __launch_bounds__(TPB) void k_df_density_error(DevView d, float offset, double* __restrict__ part) {
+__global__ __launch_bounds__(TPB) void k_df_density_error(DevView d, float offset, double* __restrict__ part, int first,
+                                                          int last) {
     __shared__ double red[TPB / 64];
     double v = 0.0;
-    for (int i = blockIdx.x * TPB + threadIdx.x; i < d.N; i += gridDim.x * TPB)
+    for (int i = first + blockIdx.x * TPB + threadIdx.x; i < last; i += gridDim.x * TPB)
         if (sph_is_fluid(__float_as_int(d.vf[i].w))) v += (double)(d.rho0 * d.eos[i].y - offset);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -771,13 +772,13 @@ int sphk_df_scale_factor(SphContext* c, float s) {
     return 0;
 }
 
-int sphk_df_density_error(SphContext* c, float offset, float* out_host) {
+int sphk_df_density_error_range(SphContext* c, float offset, int first, int count, double* out_host) {
     double h = 0.0;
-    if (c->N > 0) {
+    if (count > 0) {
         DevView d = sph_view(c);
-        int nb = (c->N + TPB - 1) / TPB;
+        int nb = (count + TPB - 1) / TPB;
         if (nb > SPH_DF_ERR_BLOCKS) nb = SPH_DF_ERR_BLOCKS;
-        hipLaunchKernelGGL(k_df_density_error, dim3(nb), dim3(TPB), 0, c->stream, d, offset, c->df_part);
+        hipLaunchKernelGGL(k_df_density_error, dim3(nb), dim3(TPB), 0, c->stream, d, offset, c->df_part, first, first + count);
         SPH_LAUNCH_CHECK(c);
         double* dev_out = nullptr;
         SPH_HIP(c, hipHostGetDevicePointer((void**)&dev_out, c->h_df_err, 0));
@@ -786,8 +787,15 @@ int sphk_df_density_error(SphContext* c, float offset, float* out_host) {
         SPH_HIP(c, hipStreamSynchronize(c->stream));
         h = *(volatile double*)c->h_df_err;
     }
-    *out_host = (float)h;
+    *out_host = h;
     return 0;
+}
+
+int sphk_df_density_error(SphContext* c, float offset, float* out_host) {
+    double h = 0.0;
+    int rc = sphk_df_density_error_range(c, offset, 0, c->N, &h);
+    *out_host = (float)h;
+    return rc;
 }
 
 int sphk_check_uniform_fluid(SphContext* c) {

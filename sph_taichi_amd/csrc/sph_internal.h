@@ -34,6 +34,7 @@ struct DevView {
     int ox, oy, oz;  // cell_origin (multi-GPU slabs)
     int tgt_lo, tgt_hi;  // local x layers whose particles are targets of this sweep ...
     int tgt_lo2, tgt_hi2;  // ... plus an optional second range (slab mode: both boundary sets in one launch)
+    int sort_by_pid;   // intra-cell order by persistent id (SPH_OPT_SORT_BY_PID)
     int drop_outside;  // slab mode: x layer outside the local grid -> virtual cell G
     int ablate;      // debug: bit0 skip phase 2, bit1 skip list write-out, bit2 skip phase 1 (profiling only)
     float grid_size, h, inv_h, d2, m_V0, rho0, stiffness, exponent, sigma, dt;
@@ -128,6 +129,7 @@ struct SphContext {
     double* df_err;     // device accumulator of compute_density_error
     // options
     int opt_gather_impl, opt_timing, opt_fused, opt_brick_shape, opt_no_dynamic, opt_ablate, opt_drop_outside;
+    int opt_sort_by_pid;
     int opt_uniform;     // SPH_OPT_UNIFORM_FLUID: -1 auto, 0 off, 1 check once
     int uniform_state;   // -1 unknown, 0 the precondition fails, 1 holds (m_uniform valid)
     float m_uniform;
@@ -170,6 +172,7 @@ int sphk_pack_advected(SphContext* c, int first, int count, void* dst);
 int sphk_eos(SphContext* c);
 int sphk_check_uniform_fluid(SphContext* c);  // sets uniform_state / m_uniform (synchronises)
 int sphk_df_density_error(SphContext* c, float offset, float* out_host);
+int sphk_df_density_error_range(SphContext* c, float offset, int first, int count, double* out_host);
 int sphk_df_scale_factor(SphContext* c, float s);
 int sphk_df_predict_velocity(SphContext* c);
 int sphk_df_advect(SphContext* c, bool fused_fluid_walls);

@@ -163,7 +163,12 @@ __global__ __launch_bounds__(TPB) void k_stable_scatter(DevView d, const int* __
     int rank = s - b;  // virtual cell G (dropped slab strays): any order will do, and the cell can be huge
     if (c != d.G) {
         rank = 0;
-        for (int t = b; t < e; ++t) rank += (idx_unstable[t] < i) ? 1 : 0;
+        if (d.sort_by_pid) {  // canonical order two ranks agree on (slab DFSPH), not the reference's
+            const int my = __float_as_int(d.aux[i].w);
+            for (int t = b; t < e; ++t) rank += (__float_as_int(d.aux[idx_unstable[t]].w) < my) ? 1 : 0;
+        } else {
+            for (int t = b; t < e; ++t) rank += (idx_unstable[t] < i) ? 1 : 0;
+        }
     }
     const int dst = b + rank;  // == grid_ids_new[i] of a serial run (particle_system.py:330)
     const float4 xm = d.xm[i];

@@ -27,6 +27,13 @@ a rigid particle is accumulated by its owner from its (ghost-layer-1) fluid
 neighbours, so nothing travels back either.  Over xGMI each message is ~HALO+1
 cell layers (C4: ~3 MB) to at most two neighbours: latency-, not bandwidth-bound.
 
+DFSPH (simulationMethod 4) across slabs: its Jacobi sweeps change velocities while positions stay put, so after
+every sweep (and after predict_velocity) the ghost layers' velocity records are refreshed from their owners -- the
+ghost range of a rank is, record for record, the owner's boundary band (same cells, and inside a cell the order by
+persistent id that SPH_OPT_SORT_BY_PID makes both sides use), a plain array copy -- and the density error of each iteration is summed over the ranks' owned particles (one 8-byte
+all-reduce), so every rank takes the same number of iterations as the single-domain solver.  Fluid and static
+solids only.
+
 Transports: `TorchTransport` (torch.distributed P2P; backend "nccl" = RCCL on
 ROCm, "gloo" for the CPU tests) and `LocalTransport` (several logical ranks in one
 process on one GPU -- how the slab logic is verified against the single-domain run
@@ -148,6 +155,29 @@ class TorchTransport:
                     bufs[p][: n_in[p] * RECORD_BYTES].copy_(bufs[(p, "stage")])
         return (bufs.get(left), n_in.get(left, 0), bufs.get(right), n_in.get(right, 0))
 
+    def swap(self, send_left, send_right, recv_left, recv_right):
+        """Fixed-size exchange with the x-neighbours (sizes known on both sides): uint8 device tensors or None."""
+        torch, dist = self.torch, self.dist
+        left, right = self._neighbours()
+        ops, stage = [], []
+        for p, sb, rb in ((left, send_left, recv_left), (right, send_right, recv_right)):
+            if p is None:
+                continue
+            if sb is not None and sb.numel() > 0:
+                ops.append(dist.P2POp(dist.isend, sb.cpu() if self.cpu_staging else sb, p))
+            if rb is not None and rb.numel() > 0:
+                t = torch.empty(rb.numel(), dtype=rb.dtype) if self.cpu_staging else rb
+                stage.append((rb, t))
+                ops.append(dist.P2POp(dist.irecv, t, p))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            if not self.cpu_staging and torch.cuda.is_available():
+                torch.cuda.current_stream().synchronize()
+        if self.cpu_staging:
+            for rb, t in stage:
+                rb.copy_(t)
+
     def all_reduce_sum(self, t):
         """In-place sum over ranks of a small device tensor (the 16 shape-matching sums of one body)."""
         if self.cpu_staging:
@@ -206,6 +236,11 @@ class SlabSolver:
         f_lo, f_hi = (halo - 1, nxl - halo + 1) if self.has_dynamic else (halo, nxl - halo)
         self.ps._call("sph_set_target_layers", halo - 1, nxl - halo + 1, f_lo, f_hi)
         self.solver = self.ps.build_solver()
+        self.dfsph = cfg.get_cfg("simulationMethod") == 4
+        if self.dfsph and self.has_dynamic:
+            raise NotImplementedError("slab mode: DFSPH with dynamic solids is not supported")
+        if self.dfsph:   # ghost velocities are refreshed record for record: both sides must order a cell the same way
+            self.ps.set_option(_lib.OPT_SORT_BY_PID, 1)
         self.nx_local = nxl
         self.capacity = capacity
         nbuf = (halo + 2) * 2 * per_layer * RECORD_BYTES + 4096
@@ -327,27 +362,32 @@ class SlabSolver:
         o = self.off
         self.stats["received"] += n_left + n_right
         nx = self.nx_local
-        layers = (C.c_int32 * 5)(H, 2 * H + 1, nx - 2 * H - 1, nx - H, nx)
+        layers = (C.c_int32 * 7)(*self._layers())
         ps._call("sph_slab_advance", o[0], o[3] - o[0],
                  C.c_void_p(recv_left.data_ptr()) if n_left > 0 else None, n_left,
-                 C.c_void_p(recv_right.data_ptr()) if n_right > 0 else None, n_right, layers, 5, 2 if density else 0)
+                 C.c_void_p(recv_right.data_ptr()) if n_right > 0 else None, n_right, layers, 7, 2 if density else 0)
         self._need_density = not density
         self._read_offsets(begin=False)
         if getattr(self, "transport", None) is not None and hasattr(self.transport, "start_counts"):
             self.transport.start_counts(*self.next_counts())   # the next exchange's sizes are known now
 
+    def _layers(self):
+        nx, H = self.nx_local, self.halo
+        return [H, 2 * H + 1, nx - 2 * H - 1, nx - H, nx, 2 * H, nx - 2 * H]   # [5], [6]: DFSPH velocity bands
+
     def _read_offsets(self, begin):
-        nx = self.nx_local
-        H = self.halo
-        layers = [H, 2 * H + 1, nx - 2 * H - 1, nx - H, nx]
+        layers = self._layers()
         if begin:
-            self.ps._call("sph_layer_offsets_begin", (C.c_int32 * 5)(*layers), 5)
-        out = (C.c_int32 * 5)()
-        self.ps._call("sph_layer_offsets_end", out, 5)
+            self.ps._call("sph_layer_offsets_begin", (C.c_int32 * 7)(*layers), 7)
+        out = (C.c_int32 * 7)()
+        self.ps._call("sph_layer_offsets_end", out, 7)
         o = list(out)
         self.ps._call("sph_truncate", o[4])               # drop the virtual cell
         self.off = o[:4]
         self.owned_range = (o[0], o[3] - o[0])
+        # DFSPH: ghost ranges and the owned bands that are the neighbours' ghosts (layers [H,2H) / [nx-2H,nx-H))
+        self.ghost = {"L": (0, o[0]), "R": (o[3], o[4] - o[3])}
+        self.band = {"L": (o[0], max(o[5] - o[0], 0)), "R": (min(o[6], o[3]), max(o[3] - o[6], 0))}
 
     # -- torch.distributed driver --------------------------------------------
     def attach(self, transport):
@@ -357,6 +397,99 @@ class SlabSolver:
         return self.transport.exchange(sL if self.has_left else None, nL, sR if self.has_right else None, nR,
                                        self._alloc_recv)
 
+    # -- DFSPH across slabs -----------------------------------------------------------------------------
+    def velocity_band(self, side):
+        """(uint8 tensor, count): the velocity records of my owned band next to `side` = that neighbour's ghosts."""
+        first, count = self.band[side]
+        buf = self.torch.empty(max(count, 1) * 16, dtype=self.torch.uint8, device=self.tdev)
+        self.ps._call("sph_copy_velocity_records", first, count, C.c_void_p(buf.data_ptr()), 0)
+        self.ps.sync()
+        return buf[: count * 16], count
+
+    def set_ghost_velocities(self, side, buf):
+        first, count = self.ghost[side]
+        if buf is None or count == 0:
+            return
+        if buf.numel() != count * 16:
+            raise RuntimeError(f"rank {self.rank}: ghost range {side} holds {count} records, the neighbour sent {buf.numel() // 16}")
+        self.ps._call("sph_copy_velocity_records", first, count, C.c_void_p(buf.data_ptr()), 1)
+
+    def _dfsph_step_requests(self):
+        """One SPHBase.step() with DFSPHSolver.substep() (sph_base.py:263-271, DFSPH.py:400-408) as a generator of
+        communication requests: ("halo_v", None) -> refresh the ghosts' velocities; ("sum", x) -> send back the sum
+        over ranks; ("records", packed) -> the usual record exchange, send back (rL, nL, rR, nR)."""
+        ps, sv = self.ps, self.solver
+        call = ps._call
+        dt = float(sv.dt[None])
+        n_fluid = max(int(ps.fluid_particle_num), 1)
+        rho0 = float(sv.density_0)
+        first, count = self.owned_range
+
+        def error(offset):
+            out = C.c_double()
+            call("sph_dfsph_compute_density_error_range", C.c_float(offset), first, count, C.byref(out))
+            return float(out.value)
+
+        call("sph_dfsph_compute_densities")
+        call("sph_dfsph_compute_DFSPH_factor")
+        it_v = it_p = 0
+        if sv.enable_divergence_solver:                       # DFSPH.py:240-283
+            call("sph_dfsph_multiply_time_step", C.c_float(1 / dt))
+            call("sph_dfsph_compute_density_change")
+            while it_v < 1 or it_v < sv.m_max_iterations_v:
+                call("sph_dfsph_divergence_solver_iteration_kernel")
+                yield ("halo_v", None)
+                call("sph_dfsph_compute_density_change")
+                total = yield ("sum", error(0.0))
+                avg = float(np.float32(total)) / n_fluid
+                if avg <= 1.0 / dt * sv.max_error_V * 0.01 * rho0:
+                    break
+                it_v += 1
+            call("sph_dfsph_multiply_time_step", C.c_float(dt))
+        call("sph_dfsph_compute_non_pressure_forces")
+        call("sph_dfsph_predict_velocity")
+        yield ("halo_v", None)
+        call("sph_dfsph_multiply_time_step", C.c_float(1 / (dt * dt)))   # DFSPH.py:324-354
+        call("sph_dfsph_compute_density_adv")
+        while it_p < 1 or it_p < sv.m_max_iterations:
+            call("sph_dfsph_pressure_solve_iteration_kernel")
+            yield ("halo_v", None)
+            call("sph_dfsph_compute_density_adv")
+            total = yield ("sum", error(rho0))
+            avg = float(np.float32(total)) / n_fluid
+            if avg <= sv.max_error * 0.01 * rho0:
+                break
+            it_p += 1
+        self.dfsph_iterations = (it_v, it_p)
+        call("sph_dfsph_advect")
+        call("sph_enforce_boundary_3D", _scene.MATERIAL_FLUID)
+        recv = yield ("records", self.pack_now())
+        self.phase_advance(*recv, density=False)
+
+    def _serve(self, gen):
+        """Drive a request generator with this rank's transport."""
+        tr = self.transport
+        try:
+            req = next(gen)
+            while True:
+                kind, arg = req
+                if kind == "halo_v":
+                    sL, _ = self.velocity_band("L") if self.has_left else (None, 0)
+                    sR, _ = self.velocity_band("R") if self.has_right else (None, 0)
+                    rL = self.torch.empty(self.ghost["L"][1] * 16, dtype=self.torch.uint8, device=self.tdev) if self.has_left else None
+                    rR = self.torch.empty(self.ghost["R"][1] * 16, dtype=self.torch.uint8, device=self.tdev) if self.has_right else None
+                    tr.swap(sL, sR, rL, rR)
+                    self.set_ghost_velocities("L", rL)
+                    self.set_ghost_velocities("R", rR)
+                    req = gen.send(None)
+                elif kind == "sum":
+                    t = self.torch.tensor([arg], dtype=self.torch.float64, device=self.tdev)
+                    req = gen.send(float(tr.all_reduce_sum(t).item()))
+                else:
+                    req = gen.send(self._exchange(*arg))
+        except StopIteration:
+            pass
+
     def step(self, n=1):
         """`self.host_ms` accumulates where the HOST spends a step: enqueueing + waiting for the packers
         ("forces_pack"), inside the exchange ("exchange"), and enqueueing the sort + waiting for its layer offsets
@@ -364,6 +497,10 @@ class SlabSolver:
         not additive GPU costs; they show whether the exchange stays inside its hiding window."""
         import time
         hm = self.host_ms
+        if self.dfsph:
+            for _ in range(n):
+                self._serve(self._dfsph_step_requests())
+            return
         for _ in range(n):
             t0 = time.perf_counter()
             if self.dynamic_bodies:
@@ -436,6 +573,32 @@ def run_local_slabs(solvers, n_steps, initialize=False):
         for s in solvers:
             s.ps._call("sph_compute_boundary_volume", 0)
         exchange_and_advance([s.init_pack() for s in solvers], False)
+        return
+    if solvers[0].dfsph:
+        for _ in range(n_steps):
+            gens = [s._dfsph_step_requests() for s in solvers]
+            reqs = [next(g) for g in gens]
+            while reqs is not None:
+                kind = reqs[0][0]
+                assert all(r[0] == kind for r in reqs), "ranks diverged"
+                if kind == "halo_v":
+                    bands = [{side: (s.velocity_band(side)[0] if ok else None)
+                              for side, ok in (("L", s.has_left), ("R", s.has_right))} for s in solvers]
+                    for r, s in enumerate(solvers):
+                        s.set_ghost_velocities("L", bands[r - 1]["R"] if r > 0 else None)
+                        s.set_ghost_velocities("R", bands[r + 1]["L"] if r + 1 < P else None)
+                    answers = [None] * P
+                elif kind == "sum":
+                    answers = [sum(r[1] for r in reqs)] * P
+                else:
+                    answers = swap([r[1] for r in reqs])
+                nxt = []
+                for g, a in zip(gens, answers):
+                    try:
+                        nxt.append(g.send(a))
+                    except StopIteration:
+                        nxt.append(None)
+                reqs = None if all(x is None for x in nxt) else nxt
         return
     for _ in range(n_steps):
         if solvers[0].dynamic_bodies:

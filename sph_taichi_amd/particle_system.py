@@ -197,9 +197,7 @@ class ParticleSystem:
             from .WCSPH import WCSPHSolver
             return WCSPHSolver(self)
         if solver_type == 4:
-            if self.slab is not None:
-                raise NotImplementedError("DFSPH is single-GPU (its solver loops need a global density error)")
-            from .DFSPH import DFSPHSolver
+            from .DFSPH import DFSPHSolver          # (on a slab rank the loops are driven by distributed.SlabSolver)
             return DFSPHSolver(self)
         raise NotImplementedError(f"Solver type {solver_type} has not been implemented.")
 

@@ -652,6 +652,10 @@ def run_slab_bench(args, rank, world, local_rank):
     import torch
     import torch.distributed as dist
     sd, n_global = slab_bench_scene(world)
+    dfsph = getattr(args, "solver", "wcsph") == "dfsph"
+    if dfsph:                                     # supplementary line, like bench.py --solver dfsph at N = 1
+        sd["Configuration"]["simulationMethod"] = 4
+        sd["Configuration"]["timeStepSize"] = 0.004
     s = SlabSolver(sd, rank, world, device=local_rank, gather_impl=args.gather_impl, brick_shape=args.brick_shape)
     s.attach(TorchTransport(torch.device("cuda", local_rank)))
     s.initialize()
@@ -674,18 +678,20 @@ def run_slab_bench(args, rank, world, local_rank):
     host_ms = dict(s.host_ms)
     # per-phase HIP events in a few EXTRA steps behind the timed region: in slab mode (two streams) the timestamping
     # barriers cost ~7 % of a step, so they stay out of the number that is reported
-    s.ps.set_option(_lib.OPT_TIMING, 1)
-    s.ps._call("sph_reset_timings")
-    s.step(min(max(args.steps, 1), 20))
-    s.ps.sync()
     tm = _lib.SphTimings()
-    s.ps._call("sph_get_timings", tm)
-    s.ps.set_option(_lib.OPT_TIMING, 0)
+    if not dfsph:
+        s.ps.set_option(_lib.OPT_TIMING, 1)
+        s.ps._call("sph_reset_timings")
+        s.step(min(max(args.steps, 1), 20))
+        s.ps.sync()
+        s.ps._call("sph_get_timings", tm)
+        s.ps.set_option(_lib.OPT_TIMING, 0)
     kt = max(int(tm.steps), 1)
     from bench import REF_PARTICLES  # noqa: E402
     steps_per_s = args.steps / dt
     line = {
-        "metric": "WCSPH steps/sec at 1.74 M particles (+ ms/step breakdown sort/neighbour/force)",
+        "metric": ("DFSPH steps/sec at 1.74 M particles (supplementary)" if dfsph else
+                   "WCSPH steps/sec at 1.74 M particles (+ ms/step breakdown sort/neighbour/force)"),
         "value": round(steps_per_s * n_global / REF_PARTICLES, 3), "unit": "steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -705,5 +711,8 @@ def run_slab_bench(args, rank, world, local_rank):
                                  "runs on the host beside the interior force sweep (rank0_host_ms_per_step.exchange)"},
         "roofline": None, "cpu_baseline": None,
     }
+    if dfsph:
+        line["config"]["solver"] = "dfsph"
+        line["config"]["last_step_iterations"] = list(getattr(s, "dfsph_iterations", (0, 0)))
     s.close()
     return line

@@ -938,11 +938,12 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
     const int nbricks = nbx * nby * nbz;
     if (nbricks > c->brick_cap) return sph_fail(c, SPH_E_INVALID, "brick list capacity exceeded");
     const int bytes = CFG::bytes(!mode_reads_list<MODE>());
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};  // per device: the attribute belongs to the function ON a device
+    const int dev = c->device >= 0 && c->device < 64 ? c->device : 0;
+    if (!attr_set[dev]) {
         SPH_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gather_brick<MODE, CFG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        attr_set = true;
+        attr_set[dev] = true;
     }
     const int grid = (nbricks + 7) / 8 * 8;
     // the list of non-empty bricks depends only on the order and the target layers: every sweep of a step that

@@ -237,8 +237,6 @@ class SlabSolver:
         self.ps._call("sph_set_target_layers", halo - 1, nxl - halo + 1, f_lo, f_hi)
         self.solver = self.ps.build_solver()
         self.dfsph = cfg.get_cfg("simulationMethod") == 4
-        if self.dfsph and self.has_dynamic:
-            raise NotImplementedError("slab mode: DFSPH with dynamic solids is not supported")
         if self.dfsph:   # ghost velocities are refreshed record for record: both sides must order a cell the same way
             self.ps.set_option(_lib.OPT_SORT_BY_PID, 1)
         self.nx_local = nxl
@@ -430,6 +428,8 @@ class SlabSolver:
             call("sph_dfsph_compute_density_error_range", C.c_float(offset), first, count, C.byref(out))
             return float(out.value)
 
+        if self.has_dynamic:
+            call("sph_compute_boundary_volume", 1)            # sph_base.py:265 (HALO 3 keeps the ghosts' volumes exact)
         call("sph_dfsph_compute_densities")
         call("sph_dfsph_compute_DFSPH_factor")
         it_v = it_p = 0
@@ -462,6 +462,9 @@ class SlabSolver:
             it_p += 1
         self.dfsph_iterations = (it_v, it_p)
         call("sph_dfsph_advect")
+        for oid in self.dynamic_bodies:                       # solve_rigid_body (sph_base.py:247-260) across ranks
+            yield ("sum_tensor", self.rigid_partial(oid))
+            self.rigid_apply(oid, 1)
         call("sph_enforce_boundary_3D", _scene.MATERIAL_FLUID)
         recv = yield ("records", self.pack_now())
         self.phase_advance(*recv, density=False)
@@ -485,6 +488,9 @@ class SlabSolver:
                 elif kind == "sum":
                     t = self.torch.tensor([arg], dtype=self.torch.float64, device=self.tdev)
                     req = gen.send(float(tr.all_reduce_sum(t).item()))
+                elif kind == "sum_tensor":                    # in place: the body's 16 shape-matching sums
+                    tr.all_reduce_sum(arg)
+                    req = gen.send(None)
                 else:
                     req = gen.send(self._exchange(*arg))
         except StopIteration:
@@ -590,6 +596,12 @@ def run_local_slabs(solvers, n_steps, initialize=False):
                     answers = [None] * P
                 elif kind == "sum":
                     answers = [sum(r[1] for r in reqs)] * P
+                elif kind == "sum_tensor":
+                    total = sum(r[1].clone() for r in reqs)
+                    for s in solvers:
+                        s.sums.copy_(total)
+                        s.torch.cuda.current_stream().synchronize()
+                    answers = [None] * P
                 else:
                     answers = swap([r[1] for r in reqs])
                 nxt = []

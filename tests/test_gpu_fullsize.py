@@ -144,3 +144,27 @@ def test_c3p_properties_at_full_size():
     solver.compute_densities()
     assert np.allclose(ps.density.to_numpy(), rho1, rtol=3e-6)
     ps.close()
+
+
+def test_dfsph_dragon_bath_equivalent():
+    """dragon_bath_dfsph.json equivalent (dt = 4e-3, 442 k particles): HIP DFSPH vs the oracle (OpenMP) over the first
+    steps -- positions to the parity tolerance, solver iteration counts within one of each other."""
+    sd = dragon_bath_scene()
+    sd["Configuration"]["simulationMethod"] = 4
+    sd["Configuration"]["timeStepSize"] = 0.004
+    cfg, sc = scenes.build(sd)
+    o = scenes.make_oracle(cfg, sc, omp_threads=_threads())
+    ps, solver = scenes.make_ps(sd)
+    o.initialize(); solver.initialize()
+    steps = 3
+    its = []
+    for _ in range(steps):
+        o.step(1)
+        its.append((o.s.last_iterations_v, o.s.last_iterations))
+    solver.step(steps)
+    st = solver.stats()
+    assert abs(st["total_iterations_v"] - sum(a + 1 for a, _ in its)) <= 1
+    assert abs(st["total_iterations"] - sum(b + 1 for _, b in its)) <= 1
+    assert scenes.rel_l2(scenes.ps_by_pid(ps, "x"), o.by_pid("x")) <= 1e-4
+    assert np.array_equal(np.sort(ps.pid.to_numpy()), np.arange(sc.particle_max_num))
+    ps.close()

@@ -139,3 +139,36 @@ def test_reference_scene_files_parse_with_expected_counts():
                 for b in cfg.get_fluid_blocks())
         if os.path.basename(f) in expect:
             assert n == expect[os.path.basename(f)], (f, n)
+
+
+def test_layer_histogram_counts_bodies_and_cuts_balance(tmp_path):
+    """scene.x_layer_histogram / slab_cuts with RigidBodies: the histogram equals the per-layer particle counts of the
+    built scene, and the cut planes split the particles evenly while respecting the minimum slab width."""
+    sd = scenes.fluid_with_rigid_bodies(str(tmp_path / "cube.obj"))
+    cfg, sc = scenes.build(sd)
+    hist = scene_mod.x_layer_histogram(SimConfig(config=sd))
+    nx = int(sc.geom.grid_num[0])
+    layers = scene_mod.x_layer_of(sc.arrays["x"][:, 0], sc.geom.grid_size, nx)
+    assert np.array_equal(hist, np.bincount(layers, minlength=nx))
+    for world, width in ((2, 3), (3, 4)):
+        cuts = scene_mod.slab_cuts(hist, world, min_width=width)
+        assert cuts[0] == 0 and cuts[-1] == nx and all(b - a >= width for a, b in zip(cuts, cuts[1:]))
+    with pytest.raises(ValueError):
+        scene_mod.slab_cuts(hist, 9, min_width=4)            # 9 slabs of >= 4 layers do not fit 25 layers
+
+
+def test_library_build_stamp_tracks_contents_not_times():
+    """build.stale() compares a content hash (a snapshot copied to another box keeps contents, not mtimes)."""
+    from sph_taichi_amd import build
+    build.build()                                            # make sure library + stamp exist
+    assert not build.stale()
+    src = os.path.join(build.CSRC, build.SOURCES[0])
+    os.utime(src, None)                                      # newer mtime, same bytes
+    assert not build.stale()
+    stamp = open(build.STAMP).read()
+    try:
+        open(build.STAMP, "w").write("0" * 64 + "\n")       # a different fingerprint => stale
+        assert build.stale()
+    finally:
+        open(build.STAMP, "w").write(stamp)
+    assert not build.stale()

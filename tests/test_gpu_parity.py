@@ -465,3 +465,28 @@ def test_two_fluid_densities_use_the_general_force_sweep():
     assert ps2.get_option(_lib.OPT_UNIFORM_FLUID_STATE) == 0
     ps2.close()
     ps.close()
+
+
+def test_empty_and_tiny_scenes():
+    """No particle at all; a single solid; two particles in flat cell 0 (whose own range the reference never visits)."""
+    cfg = {"Configuration": dict(scenes.BASE_CFG)}
+    ps, solver = scenes.make_ps(cfg)
+    assert ps.particle_max_num == 0
+    solver.initialize(); solver.step(3)
+    assert ps.x.to_numpy().shape == (0, 3) and ps.grid_particles_num.to_numpy().max() == 0
+    ps.close()
+    sd = scenes.fluid_with_rigid_blocks(fluid_counts=(1, 1, 1), static_counts=(1, 1, 1), dyn_counts=(1, 1, 1))
+    sd["FluidBlocks"] = []
+    sd["RigidBlocks"] = sd["RigidBlocks"][:1]
+    ps, solver = scenes.make_ps(sd)
+    solver.initialize(); solver.step(2)
+    assert ps.particle_max_num == 1 and np.isfinite(ps.m_V.to_numpy()).all()
+    ps.close()
+    sd = scenes.fluid_only(counts=(2, 1, 1), start=(0.005, 0.01, 0.01))      # both in cell (0,0,0)
+    cfg2, sc = scenes.build(sd)
+    o = scenes.make_oracle(cfg2, sc)
+    ps, solver = scenes.make_ps(sd)
+    o.initialize(); solver.initialize()
+    o.compute_densities(); solver.compute_densities()
+    _cmp("cell-0 density", ps.density.to_numpy(), o["density"], 1e-6)
+    ps.close()

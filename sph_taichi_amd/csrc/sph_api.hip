@@ -47,6 +47,8 @@ DevView sph_view(const SphContext* c) {
     d.m_eps = c->df.m_eps;
     d.stg = c->stg; d.gat = c->gat; d.kbuf = reinterpret_cast<float*>(c->gat);
     d.m_u = c->m_uniform; d.write_sg = 0; d.write_k = 0;
+    d.whx = p.wall_hi[0]; d.why = p.wall_hi[1]; d.whz = p.wall_hi[2];
+    d.fuse_advect = c->fuse_advect;
     return d;
 }
 
@@ -495,8 +497,20 @@ static int step_sweeps(SphContext* c, hipEvent_t* ev, const int32_t* dynamic_ids
         rc = rc ? rc : sphk_gather(c, GM_DENSITY_EOS);      // WCSPH.py:153 (+ EOS of :74-76)
         if (rc) return rc;
         if (ev) SPH_HIP(c, hipEventRecord(ev[2], c->stream));
-        rc = sphk_gather(c, GM_FORCE_FUSED);                // WCSPH.py:154-155
+        // With the one-gather force sweep no workgroup reads another particle's xm / vf (neighbours come from the
+        // stg / gat copies), so -- when no dynamic solid collects coupling reactions during the sweep -- each fluid
+        // target is integrated right in the sweep's finish: the streaming advect kernel and its launch disappear.
+        const bool fuse = c->uniform_state == 1 && c->stg_kind == 1 && c->lists_valid && c->n_dyn_host == 0 &&
+                          !c->opt_drop_outside && c->opt_gather_impl == 1 && c->N > 0;
+        c->fuse_advect = fuse ? 1 : 0;
+        rc = sphk_gather(c, GM_FORCE_FUSED);                // WCSPH.py:154-155 (+ :156 and sph_base.py:270-271 when fused)
+        c->fuse_advect = 0;
         if (rc) return rc;
+        if (fuse) {
+            if (ev) SPH_HIP(c, hipEventRecord(ev[3], c->stream));
+            sph_invalidate_lists(c);                        // positions moved
+            return 0;
+        }
     } else {
         rc = sphk_gather(c, GM_DENSITY);
         if (rc) return rc;

@@ -65,8 +65,7 @@ __device__ __forceinline__ bool mode_needs_C() {
 // the exact cell walk of a mode (overflow fallback): the uniform-fluid force sweep falls back to the general one
 template <int MODE>
 __host__ __device__ constexpr int mode_walk() {
-    return MODE == GM_FORCE_FUSED_U ? GM_FORCE_FUSED
-           : MODE == GM_DF_DIV_ITER_U ? GM_DF_DIV_ITER : MODE == GM_DF_PRESSURE_ITER_U ? GM_DF_PRESSURE_ITER : MODE;
+    return MODE == GM_DF_DIV_ITER_U ? GM_DF_DIV_ITER : MODE == GM_DF_PRESSURE_ITER_U ? GM_DF_PRESSURE_ITER : MODE;
 }
 
 // is particle (flags) a gather target of this mode?
@@ -428,7 +427,18 @@ __device__ __forceinline__ void target_finish(const DevView& d, Target& t, int i
     }
     if (MODE == GM_FORCE_FUSED || MODE == GM_FORCE_FUSED_U) {
         // fluid: a = (g + non-pressure) + pressure  (WCSPH.py:140 then :85)
-        if (gathered) d.acc[i] = make_float4(t.ax + t.px, t.ay + t.py, t.az + t.pz, 0.f);
+        if (gathered) {
+            const float4 a = make_float4(t.ax + t.px, t.ay + t.py, t.az + t.pz, 0.f);
+            d.acc[i] = a;
+            if (MODE == GM_FORCE_FUSED_U && d.fuse_advect) {  // advect (WCSPH.py:143-149) + fluid walls, see step_sweeps
+                float4 xm = make_float4(t.x, t.y, t.z, t.mV);
+                float4 vf = make_float4(t.vx, t.vy, t.vz, __int_as_float(t.flags));
+                const float hi[3] = {d.whx, d.why, d.whz};
+                advect_one<true>(d, hi, xm, vf, a);
+                d.xm[i] = xm;
+                d.vf[i] = vf;
+            }
+        }
         return;
     }
 }
@@ -463,14 +473,15 @@ __device__ __forceinline__ void gather_walk_global(const DevView& d, Target& t, 
             const int end = d.cell_end[fhi];
             for (int j = beg; j < end; ++j) {
                 if (j == i) continue;
-                const float4 A = d.xm[j];
+                // (the one-gather force sweep never reads another particle's xm / vf: its finish may overwrite them)
+                const float4 A = (MODE == GM_FORCE_FUSED_U ? d.stg : d.xm)[j];
                 const float rx = t.x - A.x, ry = t.y - A.y, rz = t.z - A.z;
                 const float r2 = rx * rx + ry * ry + rz * rz;
                 const float rinv = sph_rsq(r2);
                 const float rn = r2 * rinv;
                 if (sph_within<MODE>(d, r2, rn)) {  // particle_system.py:385
                     float4 B = make_float4(0.f, 0.f, 0.f, 0.f), Cc = B;
-                    if (mode_needs_B<MODE>()) B = d.vf[j];
+                    if (mode_needs_B<MODE>()) B = (MODE == GM_FORCE_FUSED_U ? d.gat : d.vf)[j];
                     if (mode_needs_C<MODE>()) Cc = load_C_global<MODE>(d, j);
                     pair_physics<MODE>(d, t, rx, ry, rz, r2, rn, rinv, A, B, Cc, j);
                 }

@@ -6,42 +6,7 @@
 
 #define TPB 256
 
-// sph_base.py:149-179 enforce_boundary_3D body for one particle
-__device__ __forceinline__ void wall_collide(const DevView& d, const float hi[3], float4& xm, float4& vf) {
-    const float pos[3] = {xm.x, xm.y, xm.z};
-    float x[3] = {xm.x, xm.y, xm.z};
-    float n[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        if (pos[a] > hi[a]) { n[a] += 1.0f; x[a] = hi[a]; }
-        if (pos[a] <= d.pad) { n[a] += -1.0f; x[a] = d.pad; }
-    }
-    xm.x = x[0]; xm.y = x[1]; xm.z = x[2];
-    const float len = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-    if (len > 1e-6f) {
-        // sph_base.py:118-123 simulate_collisions, c_f = 0.5
-        const float vx_ = n[0] / len, vy_ = n[1] / len, vz_ = n[2] / len;
-        const float vd = vf.x * vx_ + vf.y * vy_ + vf.z * vz_;
-        vf.x -= (1.0f + 0.5f) * vd * vx_;
-        vf.y -= (1.0f + 0.5f) * vd * vy_;
-        vf.z -= (1.0f + 0.5f) * vd * vz_;
-    }
-}
-
 struct WallHi { float v[3]; };
-
-// WCSPH.py:143-149 advect; FLUID_WALLS additionally applies
-// enforce_boundary_3D(material_fluid) (sph_base.py:270-271) to fluid particles in
-// the same pass (it only touches fluid, so it commutes with the rigid solve).
-// one particle's symplectic-Euler update (+ fluid wall pass); shared by the in-place kernel and the packer
-template <bool FLUID_WALLS>
-__device__ __forceinline__ void advect_one(const DevView& d, const float hi[3], float4& xm, float4& vf, const float4 a) {
-    const int fl = __float_as_int(vf.w);
-    if (!sph_flags_dynamic(fl)) return;
-    vf.x += d.dt * a.x; vf.y += d.dt * a.y; vf.z += d.dt * a.z;
-    xm.x += d.dt * vf.x; xm.y += d.dt * vf.y; xm.z += d.dt * vf.z;
-    if (FLUID_WALLS && sph_is_fluid(fl)) wall_collide(d, hi, xm, vf);
-}
 
 template <bool FLUID_WALLS>
 __global__ __launch_bounds__(TPB) void k_advect(DevView d, WallHi hi) {

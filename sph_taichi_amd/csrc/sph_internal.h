@@ -44,6 +44,8 @@ struct DevView {
     float w_zero, w_d;  // W(0), W(d)
     float m_eps;        // DFSPH.py:17
     float m_u;          // the common fluid particle mass (uniform-fluid force path)
+    float whx, why, whz;  // upper wall planes (domain_size - padding), for the advect fused into the force sweep
+    int fuse_advect;    // GM_FORCE_FUSED_U finish also integrates its fluid targets (WCSPH.py:143-149 + fluid walls)
     int write_sg;       // density finish also writes the stg (/ gat) records of the one-gather sweeps
     int write_k;        // density-change / -advection finish also writes k_j into kbuf
     float4* xm;
@@ -130,6 +132,7 @@ struct SphContext {
     // options
     int opt_gather_impl, opt_timing, opt_fused, opt_brick_shape, opt_no_dynamic, opt_ablate, opt_drop_outside;
     int opt_sort_by_pid;
+    int fuse_advect;     // set around the force launch of sph_step when the advect can ride in its finish
     int opt_uniform;     // SPH_OPT_UNIFORM_FLUID: -1 auto, 0 off, 1 check once
     int uniform_state;   // -1 unknown, 0 the precondition fails, 1 holds (m_uniform valid)
     float m_uniform;
@@ -239,4 +242,42 @@ __device__ __forceinline__ int sph_wave_inclusive_scan(int v, int lane) {
     }
     return v;
 }
+
+// sph_base.py:149-179 enforce_boundary_3D body for one particle
+__device__ __forceinline__ void wall_collide(const DevView& d, const float hi[3], float4& xm, float4& vf) {
+    const float pos[3] = {xm.x, xm.y, xm.z};
+    float x[3] = {xm.x, xm.y, xm.z};
+    float n[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (pos[a] > hi[a]) { n[a] += 1.0f; x[a] = hi[a]; }
+        if (pos[a] <= d.pad) { n[a] += -1.0f; x[a] = d.pad; }
+    }
+    xm.x = x[0]; xm.y = x[1]; xm.z = x[2];
+    const float len = sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    if (len > 1e-6f) {
+        // sph_base.py:118-123 simulate_collisions, c_f = 0.5
+        const float vx_ = n[0] / len, vy_ = n[1] / len, vz_ = n[2] / len;
+        const float vd = vf.x * vx_ + vf.y * vy_ + vf.z * vz_;
+        vf.x -= (1.0f + 0.5f) * vd * vx_;
+        vf.y -= (1.0f + 0.5f) * vd * vy_;
+        vf.z -= (1.0f + 0.5f) * vd * vz_;
+    }
+}
+
+
+// WCSPH.py:143-149 advect; FLUID_WALLS additionally applies
+// enforce_boundary_3D(material_fluid) (sph_base.py:270-271) to fluid particles in
+// the same pass (it only touches fluid, so it commutes with the rigid solve).
+// one particle's symplectic-Euler update (+ fluid wall pass); shared by the in-place kernel and the packer
+template <bool FLUID_WALLS>
+__device__ __forceinline__ void advect_one(const DevView& d, const float hi[3], float4& xm, float4& vf, const float4 a) {
+    const int fl = __float_as_int(vf.w);
+    if (!sph_flags_dynamic(fl)) return;
+    vf.x += d.dt * a.x; vf.y += d.dt * a.y; vf.z += d.dt * a.z;
+    xm.x += d.dt * vf.x; xm.y += d.dt * vf.y; xm.z += d.dt * vf.z;
+    if (FLUID_WALLS && sph_is_fluid(fl)) wall_collide(d, hi, xm, vf);
+}
+
+
 #endif  // __HIPCC__

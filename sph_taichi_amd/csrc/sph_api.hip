@@ -490,6 +490,7 @@ static int uniform_fluid(SphContext* c) {
 // sweeps of one step after the sort; ev (nullable) = the step's 5 events, ev[1] already recorded
 static int step_sweeps(SphContext* c, hipEvent_t* ev, const int32_t* dynamic_ids, int32_t n_dynamic) {
     int rc = 0;
+    bool fused_advect = false;
     // compute_moving_boundary_volume()                     sph_base.py:265
     if (c->n_dyn_host > 0) { rc = sphk_gather(c, GM_BVOL_DYNAMIC); if (rc) return rc; }
     if (c->opt_fused) {
@@ -498,19 +499,16 @@ static int step_sweeps(SphContext* c, hipEvent_t* ev, const int32_t* dynamic_ids
         if (rc) return rc;
         if (ev) SPH_HIP(c, hipEventRecord(ev[2], c->stream));
         // With the one-gather force sweep no workgroup reads another particle's xm / vf (neighbours come from the
-        // stg / gat copies), so -- when no dynamic solid collects coupling reactions during the sweep -- each fluid
-        // target is integrated right in the sweep's finish: the streaming advect kernel and its launch disappear.
-        const bool fuse = c->uniform_state == 1 && c->stg_kind == 1 && c->lists_valid && c->n_dyn_host == 0 &&
-                          !c->opt_drop_outside && c->opt_gather_impl == 1 && c->N > 0;
+        // stg / gat copies), so each fluid target is integrated right in the sweep's finish and the streaming advect
+        // kernel disappears.  Dynamic rigid particles collect coupling reactions from many workgroups during the sweep:
+        // they are integrated afterwards, by a kernel over their (short) list.
+        const bool fuse = c->uniform_state == 1 && c->stg_kind == 1 && c->lists_valid && !c->opt_drop_outside &&
+                          c->opt_gather_impl == 1 && c->N > 0;
         c->fuse_advect = fuse ? 1 : 0;
         rc = sphk_gather(c, GM_FORCE_FUSED);                // WCSPH.py:154-155 (+ :156 and sph_base.py:270-271 when fused)
         c->fuse_advect = 0;
         if (rc) return rc;
-        if (fuse) {
-            if (ev) SPH_HIP(c, hipEventRecord(ev[3], c->stream));
-            sph_invalidate_lists(c);                        // positions moved
-            return 0;
-        }
+        fused_advect = fuse;
     } else {
         rc = sphk_gather(c, GM_DENSITY);
         if (rc) return rc;
@@ -522,7 +520,7 @@ static int step_sweeps(SphContext* c, hipEvent_t* ev, const int32_t* dynamic_ids
     }
     if (ev) SPH_HIP(c, hipEventRecord(ev[3], c->stream));
     // advect (WCSPH.py:156) + enforce_boundary_3D(fluid) (sph_base.py:270-271) in one pass
-    rc = sphk_advect(c, true);
+    rc = fused_advect ? sphk_advect_dyn_list(c) : sphk_advect(c, true);
     if (rc) return rc;
     // solve_rigid_body()                                   sph_base.py:247-260
     if (c->n_dyn_host > 0)

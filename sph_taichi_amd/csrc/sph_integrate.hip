@@ -119,6 +119,19 @@ __global__ __launch_bounds__(64) void k_df_density_error_total(const double* __r
     if (threadIdx.x == 0) *out = v;
 }
 
+// advect of the dynamic rigid particles alone (the fluid was integrated inside the force sweep)
+__global__ __launch_bounds__(TPB) void k_advect_list(DevView d, WallHi hi, const int* __restrict__ list, int n) {
+    const int tix = blockIdx.x * TPB + threadIdx.x;
+    if (tix >= n) return;
+    const int i = list[tix];
+    float4 vf = d.vf[i];
+    if (!sph_is_dynamic_rigid(__float_as_int(vf.w))) return;
+    float4 xm = d.xm[i];
+    advect_one<false>(d, hi.v, xm, vf, d.acc[i]);
+    d.xm[i] = xm;
+    d.vf[i] = vf;
+}
+
 // Slab halo packer: records [first, first+count) AS THEY WILL BE after this step's advect, written to dst
 // (count xm, then count vf, then count aux) without touching the arrays -- the interior force sweep that runs
 // concurrently with the exchange still needs the old positions; k_advect later repeats the same update in place.
@@ -578,6 +591,16 @@ int sphk_advect(SphContext* c, bool fused_fluid_walls) {
     else hipLaunchKernelGGL(k_advect<false>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c));
     SPH_LAUNCH_CHECK(c);
     sph_invalidate_lists(c);
+    return 0;
+}
+
+int sphk_advect_dyn_list(SphContext* c) {
+    sph_invalidate_lists(c);
+    if (c->n_dyn_host <= 0) return 0;
+    DevView d = sph_view(c);
+    hipLaunchKernelGGL(k_advect_list, dim3((c->n_dyn_host + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, wall_hi(c), c->dyn_list,
+                       c->n_dyn_host);
+    SPH_LAUNCH_CHECK(c);
     return 0;
 }
 

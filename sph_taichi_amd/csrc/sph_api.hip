@@ -774,12 +774,30 @@ int32_t sph_slab_forces(SphContext* c, int32_t bl_lo, int32_t bl_hi, int32_t br_
     c->use_side = false;
     if (rc) return rc;
     SPH_HIP(c, hipEventRecord(c->ev_pack, no_side ? c->stream : c->side));
-    rc = sphk_gather_layers(c, GM_FORCE_FUSED, bl_hi, br_lo, 0, 0);  // interior: overlaps with the exchange
+    // interior: overlaps with the exchange; with the one-gather sweep its finish integrates its own targets (see
+    // step_sweeps), so that afterwards only the two boundary ranges -- exactly the packed ranges -- are left to advect
+    // (ghost records are not advected at all: the exchange replaces them)
+    const bool fuse = c->uniform_state == 1 && c->stg_kind == 1 && c->lists_valid && c->opt_no_dynamic;
+    c->fuse_advect = fuse ? 1 : 0;
+    rc = sphk_gather_layers(c, GM_FORCE_FUSED, bl_hi, br_lo, 0, 0);
+    c->fuse_advect = 0;
     if (rc) return rc;
     SPH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pack, 0));  // the packers read what the advect overwrites
     hipEvent_t* ev = c->slab_ev_open ? c->ev[c->ev_used] : nullptr;
     if (ev) SPH_HIP(c, hipEventRecord(ev[3], c->stream));  // force = interior sweep (+ the wait for the side stream)
-    rc = sphk_advect(c, true);
+    if (fuse) {
+        // (in a slab only HALO+1 layers wide the two packed ranges overlap: advect their union once)
+        const int a0 = firstL, a1 = firstL + nL, b0 = firstR, b1 = firstR + nR;
+        if (nL > 0 && nR > 0 && b0 < a1) {
+            const int lo = a0 < b0 ? a0 : b0, hi = a1 > b1 ? a1 : b1;
+            rc = sphk_advect_range(c, lo, hi - lo);
+        } else {
+            rc = sphk_advect_range(c, firstL, nL);
+            rc = rc ? rc : sphk_advect_range(c, firstR, nR);
+        }
+    } else {
+        rc = sphk_advect(c, true);
+    }
     if (!rc && ev) { SPH_HIP(c, hipEventRecord(ev[4], c->stream)); c->ev_used++; c->slab_ev_open = false; }
     return rc;
 }

@@ -119,6 +119,19 @@ __global__ __launch_bounds__(64) void k_df_density_error_total(const double* __r
     if (threadIdx.x == 0) *out = v;
 }
 
+// advect (+ fluid walls) of a contiguous record range (slab mode: the boundary layers, after their packers)
+__global__ __launch_bounds__(TPB) void k_advect_range(DevView d, WallHi hi, int first, int count) {
+    const int k = blockIdx.x * TPB + threadIdx.x;
+    if (k >= count) return;
+    const int i = first + k;
+    float4 vf = d.vf[i];
+    if (!sph_flags_dynamic(__float_as_int(vf.w))) return;
+    float4 xm = d.xm[i];
+    advect_one<true>(d, hi.v, xm, vf, d.acc[i]);
+    d.xm[i] = xm;
+    d.vf[i] = vf;
+}
+
 // advect of the dynamic rigid particles alone (the fluid was integrated inside the force sweep)
 __global__ __launch_bounds__(TPB) void k_advect_list(DevView d, WallHi hi, const int* __restrict__ list, int n) {
     const int tix = blockIdx.x * TPB + threadIdx.x;
@@ -591,6 +604,15 @@ int sphk_advect(SphContext* c, bool fused_fluid_walls) {
     else hipLaunchKernelGGL(k_advect<false>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c));
     SPH_LAUNCH_CHECK(c);
     sph_invalidate_lists(c);
+    return 0;
+}
+
+int sphk_advect_range(SphContext* c, int first, int count) {
+    sph_invalidate_lists(c);
+    if (count <= 0) return 0;
+    DevView d = sph_view(c);
+    hipLaunchKernelGGL(k_advect_range, dim3((count + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, wall_hi(c), first, count);
+    SPH_LAUNCH_CHECK(c);
     return 0;
 }
 

@@ -181,6 +181,7 @@ int sphk_df_predict_velocity(SphContext* c);
 int sphk_df_advect(SphContext* c, bool fused_fluid_walls);
 int sphk_advect(SphContext* c, bool fused_fluid_walls);
 int sphk_advect_dyn_list(SphContext* c);  // dynamic rigid particles only
+int sphk_advect_range(SphContext* c, int first, int count);
 int sphk_enforce_boundary(SphContext* c, int particle_type);
 int sphk_rigid_com(SphContext* c, int object_id, bool to_rest);
 int sphk_rigid_solve(SphContext* c, int object_id);

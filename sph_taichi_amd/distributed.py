@@ -319,7 +319,10 @@ class SlabSolver:
         self._ensure_send_bufs(nL, nR)
         nx = self.nx_local
         extra = 1 if self.has_dynamic else 0      # coupling reactions on boundary solids come from one layer further in
-        ps._call("sph_slab_forces", H, 2 * H + 1 + extra, nx - 2 * H - 1 - extra, nx - H,
+        # a side without a neighbour has no boundary set (its layers are interior: nothing to pack, nothing to hurry)
+        bl = (H, 2 * H + 1 + extra) if (self.has_left or not pack) else (H, H)
+        br = (nx - 2 * H - 1 - extra, nx - H) if (self.has_right or not pack) else (nx - H, nx - H)
+        ps._call("sph_slab_forces", bl[0], bl[1], br[0], br[1],
                  self.off[0], nL, C.c_void_p(self.send_buf["L"].data_ptr()),
                  self.off[2], nR, C.c_void_p(self.send_buf["R"].data_ptr()))
         ps._call("sph_slab_wait_pack")

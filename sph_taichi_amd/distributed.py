@@ -702,7 +702,24 @@ def run_slab_bench(args, rank, world, local_rank):
         s.ps._call("sph_get_timings", tm)
         s.ps.set_option(_lib.OPT_TIMING, 0)
     kt = max(int(tm.steps), 1)
-    from bench import REF_PARTICLES  # noqa: E402
+    from bench import REF_PARTICLES, HBM_PEAK_GBS  # noqa: E402
+    roofline = None
+    if not dfsph and tm.neighbour_ms > 0 and tm.force_ms > 0:
+        # rank 0's dominant sweep over its local records (owned + ghosts) and local cells, algorithmic bytes as at
+        # N = 1 (density+EOS 32 N + 4 G, fused force 60 N + 4 G); in slab mode the force phase is an
+        # interior launch plus a boundary launch on a side stream, so its figure is per phase, not per launch
+        n_loc = s.ps.count()
+        g_loc = int(np.prod(s.ps._local_grid_num))
+        cands = {"k_gather_brick<GM_DENSITY_EOS>": (32.0 * n_loc + 4.0 * g_loc, tm.neighbour_ms / kt),
+                 "k_gather_brick<GM_FORCE_FUSED*> (interior + boundary launches)": (60.0 * n_loc + 4.0 * g_loc,
+                                                                                    tm.force_ms / kt)}
+        dom = max(cands, key=lambda k_: cands[k_][1])
+        ab, ms = cands[dom]
+        ach = ab / (ms * 1e-3) / 1e9
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "rank": 0, "alg_bytes_per_launch": ab,
+                    "avg_launch_ms": round(ms, 4), "local_records": n_loc, "local_cells": g_loc,
+                    "note": "rank 0; gather sweeps are VALU-issue-bound, not HBM-bound (DESIGN.md section 4)"}
     steps_per_s = args.steps / dt
     line = {
         "metric": ("DFSPH steps/sec at 1.74 M particles (supplementary)" if dfsph else
@@ -724,7 +741,7 @@ def run_slab_bench(args, rank, world, local_rank):
                          "sum_of_phases": round(tm.total_ms / kt, 4),
                          "note": "HIP events on rank 0's stream over extra steps after the timed region; the exchange "
                                  "runs on the host beside the interior force sweep (rank0_host_ms_per_step.exchange)"},
-        "roofline": None, "cpu_baseline": None,
+        "roofline": roofline, "cpu_baseline": None,
     }
     if dfsph:
         line["config"]["solver"] = "dfsph"

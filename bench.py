@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--solver", default="wcsph", choices=["wcsph", "dfsph"],
                     help="dfsph: the same workload under DFSPHSolver (simulationMethod 4, dt = 4e-3) -- a supplementary "
                          "line, not BASELINE.json's metric")
+    ap.add_argument("--recut-every", type=int, default=0,
+                    help="--gpus N: re-cut the slabs every K steps (0 = never: the tiled workload is balanced by construction)")
     ap.add_argument("--gather-impl", type=int, default=1)
     ap.add_argument("--brick-shape", type=int, default=0)
     ap.add_argument("--fused", type=int, default=1)

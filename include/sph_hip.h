@@ -215,6 +215,11 @@ int32_t sph_append_records(SphContext* ctx, const void* device_src, int32_t coun
  * restricted).  A slab rank sets density = owned + first ghost layer, force = owned: the outer ghost layer only
  * serves as neighbours.  Default: all layers. */
 int32_t sph_set_target_layers(SphContext* ctx, int32_t density_lo, int32_t density_hi, int32_t force_lo, int32_t force_hi);
+/* Re-cut (load balance, SURVEY 8e "re-cut every K steps"): move the context's window of global x layers to
+ * [origin_x, origin_x + nx), nx <= the grid_num[0] given to sph_create (which is the allocation).  Takes effect at
+ * the next sort: records outside the new window fall into the virtual cell and are dropped like any stray.  Resets
+ * the target layers to all layers (call sph_set_target_layers afterwards). */
+int32_t sph_slab_set_window(SphContext* ctx, int32_t origin_x, int32_t nx);
 /* One slab step's device work in two calls (same effect as the individual calls, fewer host round trips):
  *   sph_slab_pack : pack [firstL, firstL+nL) into dstL and [firstR, ...) into dstR, then synchronise (the
  *                   buffers are handed to the transport next);

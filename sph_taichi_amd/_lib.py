@@ -95,6 +95,7 @@ SYMBOLS = [
     ("sph_pack_range", C.c_int32, [_ctx, C.c_int32, C.c_int32, C.c_void_p]),
     ("sph_append_records", C.c_int32, [_ctx, C.c_void_p, C.c_int32]),
     ("sph_set_target_layers", C.c_int32, [_ctx, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    ("sph_slab_set_window", C.c_int32, [_ctx, C.c_int32, C.c_int32]),
     ("sph_slab_pack", C.c_int32, [_ctx, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     ("sph_slab_advance", C.c_int32, [_ctx, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                      C.POINTER(C.c_int32), C.c_int32, C.c_int32]),

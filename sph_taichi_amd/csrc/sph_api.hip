@@ -105,6 +105,7 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     c->N = params->n_particles;
     c->cap = params->capacity > 0 ? params->capacity : 1;
     c->G = params->grid_num[0] * params->grid_num[1] * params->grid_num[2];
+    c->nx_alloc = params->grid_num[0];
     c->tgt_layers[0] = c->tgt_layers[2] = 0;
     c->tgt_layers[1] = c->tgt_layers[3] = params->grid_num[0];
     c->opt_gather_impl = 1;
@@ -537,6 +538,24 @@ int32_t sph_set_target_layers(SphContext* c, int32_t dlo, int32_t dhi, int32_t f
     const int nx = c->p.grid_num[0];
     if (dlo < 0 || dhi > nx || dlo > dhi || flo < 0 || fhi > nx || flo > fhi) return sph_fail(c, SPH_E_INVALID, "sph_set_target_layers: bad range");
     c->tgt_layers[0] = dlo; c->tgt_layers[1] = dhi; c->tgt_layers[2] = flo; c->tgt_layers[3] = fhi;
+    return 0;
+}
+
+int32_t sph_slab_set_window(SphContext* c, int32_t origin_x, int32_t nx) {
+    ENTER(c);
+    if (nx <= 0 || nx > c->nx_alloc) return sph_fail(c, SPH_E_INVALID, "sph_slab_set_window: nx exceeds the allocation of sph_create");
+    c->p.cell_origin[0] = origin_x;
+    c->p.grid_num[0] = nx;
+    c->G = nx * c->p.grid_num[1] * c->p.grid_num[2];
+    c->scan_blocks = (c->G + 1 + SCAN_TILE - 1) / SCAN_TILE;  // <= the allocation's
+    c->tgt_layers[0] = c->tgt_layers[2] = 0;
+    c->tgt_layers[1] = c->tgt_layers[3] = nx;
+    // every cell id changes meaning: nothing derived from the old window survives, and the spare cell array was
+    // zeroed for the old padded size only
+    c->next_cells_zero = false;
+    sph_invalidate_lists(c);
+    c->have_keys = c->have_prefix = c->sorted = false;
+    c->n_dyn_host = -1;
     return 0;
 }
 

@@ -82,6 +82,7 @@ struct SphContext {
     int* brick_count2;
     int off_zero_mask;   // which of the pending offsets are layer 0 (no copy needed)
     int tgt_layers[4];  // density lo/hi, force lo/hi (slab mode); default 0..nx
+    int nx_alloc;       // grid_num[0] at sph_create: what the cell arrays and brick lists are sized for (sph_slab_set_window)
     int in_off;  // first live record of the current set (non-zero only between sph_select_range and the next sort)
     float4* xm[2];
     float4* vf[2];

@@ -191,11 +191,47 @@ class TorchTransport:
         return t
 
 
+def plan_recut(cuts, hist, world, halo, width_cap=None):
+    """New cut planes, each at most ONE cell layer from the old one, towards the cuts that balance the particle
+    counts of `hist` (particles per global x layer).  One layer per event is what the running exchange can absorb:
+    the rank that gains a layer already holds it as a ghost, and its neighbour packs one layer deeper for that one
+    exchange.  A cut only moves into a slab that is at least halo + 2 layers wide (the deeper pack must come from
+    owned layers), no slab drops below halo + 1 layers or grows beyond `width_cap[i]` (its allocation).
+    Pure function of its arguments: every rank computes the same answer from the all-reduced histogram."""
+    target = _scene.slab_cuts(hist, world, min_width=halo + 1)
+    w = [cuts[i + 1] - cuts[i] for i in range(world)]
+    d = [0] * (world + 1)
+    for i in range(1, world):
+        if target[i] > cuts[i] and w[i] >= halo + 2:
+            d[i] = 1            # moves right: slab i gives its first layer to slab i-1
+        elif target[i] < cuts[i] and w[i - 1] >= halo + 2:
+            d[i] = -1
+    changed = True
+    while changed:
+        changed = False
+        for i in range(world):
+            nw = w[i] + d[i + 1] - d[i]
+            if nw < halo + 1:                                   # cancel what shrinks slab i
+                if d[i] == 1:
+                    d[i], changed = 0, True
+                if d[i + 1] == -1:
+                    d[i + 1], changed = 0, True
+            elif width_cap is not None and nw > width_cap[i]:   # cancel what widens it
+                if d[i] == -1:
+                    d[i], changed = 0, True
+                if d[i + 1] == 1:
+                    d[i + 1], changed = 0, True
+    return [c + k for c, k in zip(cuts, d)]
+
+
 class SlabSolver:
     """One rank of the slab-decomposed WCSPH solver."""
 
     def __init__(self, scene_dict, rank, world, device=0, cuts=None, capacity_factor=1.5, use_torch_stream=False,
-                 gather_impl=1, brick_shape=0, scene_dir=None):
+                 gather_impl=1, brick_shape=0, scene_dir=None, recut_every=0, nx_slack=16):
+        """`recut_every` = K > 0: every K steps the ranks add up their per-layer particle counts and every cut plane
+        moves ONE cell layer towards the position that balances the particle counts (`plan_recut`); the slab may
+        grow by `nx_slack` layers over its initial width before the allocation is the limit."""
         import torch
         self.torch = torch
         self.rank, self.world = rank, world
@@ -215,12 +251,20 @@ class SlabSolver:
             raise ValueError(f"slab {rank} is {self.x_hi - self.x_lo} layers wide; need >= {halo + 1}")
         own = int(hist[self.x_lo:self.x_hi].sum())
         per_layer = int(hist.max())
+        if int(recut_every) > 0:      # a re-cut balances towards N / world owned particles, whatever the start was
+            own = max(own, -(-int(hist.sum()) // world))
         capacity = int(capacity_factor * own) + (2 * halo + 2) * 2 * per_layer + 1024
         self.device = device
         self.tdev = torch.device("cuda", device)
         stream = torch.cuda.current_stream(self.tdev).cuda_stream if use_torch_stream else None
+        self.recut_every = int(recut_every)
+        self.width_cap = [self.cuts[i + 1] - self.cuts[i] + int(nx_slack) for i in range(world)]   # allocations
+        self.steps_done = 0
+        self._shift = (0, 0)        # pending move of (left cut, right cut), applied at the next exchange
+        self._recut_due = False
         self.ps = ParticleSystem(cfg, device=device, stream=stream, scene_dir=scene_dir,
-                                 slab=dict(x_lo=self.x_lo, x_hi=self.x_hi, halo=halo, capacity=capacity))
+                                 slab=dict(x_lo=self.x_lo, x_hi=self.x_hi, halo=halo, capacity=capacity,
+                                           nx_slack=int(nx_slack) if self.recut_every > 0 else 0))
         self.ps.set_option(_lib.OPT_GATHER_IMPL, gather_impl)
         self.ps.set_option(_lib.OPT_BRICK_SHAPE, brick_shape)
         self.ps.set_option(_lib.OPT_NO_DYNAMIC_SOLIDS, 0 if self.has_dynamic else 1)
@@ -229,12 +273,7 @@ class SlabSolver:
         # mass); then the device checks the local particles once and later arrivals are vouched for
         same_mass = len({float(b["density"]) for b in cfg.get_fluid_blocks()}) <= 1
         self.ps.set_option(_lib.OPT_UNIFORM_FLUID, 1 if same_mass else 0)
-        nxl = self.x_hi - self.x_lo + 2 * halo
-        # targets: density on owned + ghost layer 1 (its rho/p feed the owned forces); forces on owned only,
-        # or also on ghost layer 1 when dynamic solids exist (their owner accumulates the coupling reaction
-        # from its ghost fluid neighbours)
-        f_lo, f_hi = (halo - 1, nxl - halo + 1) if self.has_dynamic else (halo, nxl - halo)
-        self.ps._call("sph_set_target_layers", halo - 1, nxl - halo + 1, f_lo, f_hi)
+        nxl = self._set_target_layers()
         self.solver = self.ps.build_solver()
         self.dfsph = cfg.get_cfg("simulationMethod") == 4
         if self.dfsph:   # ghost velocities are refreshed record for record: both sides must order a cell the same way
@@ -264,6 +303,16 @@ class SlabSolver:
                           rest.ctypes.data_as(C.c_void_p), int(rest.shape[0]))
 
     # -- helpers ------------------------------------------------------------
+    def _set_target_layers(self):
+        """targets: density on owned + ghost layer 1 (its rho/p feed the owned forces); forces on owned only,
+        or also on ghost layer 1 when dynamic solids exist (their owner accumulates the coupling reaction
+        from its ghost fluid neighbours)"""
+        halo = self.halo
+        nxl = self.x_hi - self.x_lo + 2 * halo
+        f_lo, f_hi = (halo - 1, nxl - halo + 1) if self.has_dynamic else (halo, nxl - halo)
+        self.ps._call("sph_set_target_layers", halo - 1, nxl - halo + 1, f_lo, f_hi)
+        return nxl
+
     def _offsets(self, layers):
         arr = (C.c_int32 * len(layers))(*layers)
         out = (C.c_int32 * len(layers))()
@@ -286,9 +335,18 @@ class SlabSolver:
     #   (exchange)   : starts as soon as the packers are done -> hidden behind the interior force sweep
     #   phase_advance: keep the old owned range, append the neighbours' ranges, sort once (position decides
     #                  ownership, strays fall into the virtual cell), density sweep; read the new offsets back
+    def pack_ranges(self):
+        """(firstL, nL, firstR, nR) of the next exchange: the H + 1 owned layers next to each neighbour -- its H
+        ghost layers plus one layer of migration margin -- and one layer more on a side whose cut plane is about
+        to move INTO this slab (the neighbour then owns this slab's first layer and needs ghosts one layer deeper)."""
+        o, (sL, sR) = self.off, self._shift
+        endL = min(self.off_ext[0], o[3]) if sL > 0 else o[1]
+        firstR = max(self.off_ext[1], o[0]) if sR < 0 else o[2]
+        return (o[0], (endL - o[0]) if self.has_left else 0, firstR, (o[3] - firstR) if self.has_right else 0)
+
     def next_counts(self):
-        o = self.off
-        return ((o[1] - o[0]) if self.has_left else 0, (o[3] - o[2]) if self.has_right else 0)
+        _, nL, _, nR = self.pack_ranges()
+        return nL, nR
 
     def _ensure_send_bufs(self, nL, nR):
         for side, n in (("L", nL), ("R", nR)):
@@ -301,10 +359,10 @@ class SlabSolver:
         ps = self.ps
         ps._call("sph_sort")
         self._read_offsets(begin=True)
-        nL, nR = self.next_counts()
+        fL, nL, fR, nR = self.pack_ranges()
         self._ensure_send_bufs(nL, nR)
-        ps._call("sph_slab_pack", self.off[0], nL, C.c_void_p(self.send_buf["L"].data_ptr()),
-                 self.off[2], nR, C.c_void_p(self.send_buf["R"].data_ptr()))
+        ps._call("sph_slab_pack", fL, nL, C.c_void_p(self.send_buf["L"].data_ptr()),
+                 fR, nR, C.c_void_p(self.send_buf["R"].data_ptr()))
         self.stats["sent"] += nL + nR
         return self.send_buf["L"], nL, self.send_buf["R"], nR
 
@@ -315,26 +373,27 @@ class SlabSolver:
         if self._need_density:
             ps._call("sph_slab_density")
             self._need_density = False
-        nL, nR = self.next_counts() if pack else (0, 0)
+        fL, nL, fR, nR = self.pack_ranges() if pack else (self.off[0], 0, self.off[2], 0)
         self._ensure_send_bufs(nL, nR)
         nx = self.nx_local
         extra = 1 if self.has_dynamic else 0      # coupling reactions on boundary solids come from one layer further in
+        sL, sR = self._shift                      # a re-cut in flight: that side packs one layer more
         # a side without a neighbour has no boundary set (its layers are interior: nothing to pack, nothing to hurry)
-        bl = (H, 2 * H + 1 + extra) if (self.has_left or not pack) else (H, H)
-        br = (nx - 2 * H - 1 - extra, nx - H) if (self.has_right or not pack) else (nx - H, nx - H)
+        bl = (H, 2 * H + 1 + extra + max(sL, 0)) if (self.has_left or not pack) else (H, H)
+        br = (nx - 2 * H - 1 - extra - max(-sR, 0), nx - H) if (self.has_right or not pack) else (nx - H, nx - H)
         ps._call("sph_slab_forces", bl[0], bl[1], br[0], br[1],
-                 self.off[0], nL, C.c_void_p(self.send_buf["L"].data_ptr()),
-                 self.off[2], nR, C.c_void_p(self.send_buf["R"].data_ptr()))
+                 fL, nL, C.c_void_p(self.send_buf["L"].data_ptr()),
+                 fR, nR, C.c_void_p(self.send_buf["R"].data_ptr()))
         ps._call("sph_slab_wait_pack")
         self.stats["sent"] += nL + nR
         return self.send_buf["L"], nL, self.send_buf["R"], nR
 
     def pack_now(self):
         """Pack the boundary layers as they are now (after advect + rigid solve); synchronises."""
-        nL, nR = self.next_counts()
+        fL, nL, fR, nR = self.pack_ranges()
         self._ensure_send_bufs(nL, nR)
-        self.ps._call("sph_slab_pack", self.off[0], nL, C.c_void_p(self.send_buf["L"].data_ptr()),
-                      self.off[2], nR, C.c_void_p(self.send_buf["R"].data_ptr()))
+        self.ps._call("sph_slab_pack", fL, nL, C.c_void_p(self.send_buf["L"].data_ptr()),
+                      fR, nR, C.c_void_p(self.send_buf["R"].data_ptr()))
         self.stats["sent"] += nL + nR
         return self.send_buf["L"], nL, self.send_buf["R"], nR
 
@@ -362,29 +421,73 @@ class SlabSolver:
         H = self.halo
         o = self.off
         self.stats["received"] += n_left + n_right
-        nx = self.nx_local
-        layers = (C.c_int32 * 7)(*self._layers())
+        if self._shift != (0, 0):
+            # the re-cut takes effect with this sort: the window moves, the kept (old owned) range and the received
+            # ranges are re-classified by position -- a lost layer stays behind as a ghost, a gained one arrived
+            # with the neighbour's (one layer deeper) pack
+            self.x_lo += self._shift[0]
+            self.x_hi += self._shift[1]
+            self.ps.set_slab_window(self.x_lo, self.x_hi)
+            self.nx_local = self._set_target_layers()
+            self._shift = (0, 0)
+            self.stats["recuts"] = self.stats.get("recuts", 0) + 1
+        nl = len(self._layers())
+        layers = (C.c_int32 * nl)(*self._layers())
         ps._call("sph_slab_advance", o[0], o[3] - o[0],
                  C.c_void_p(recv_left.data_ptr()) if n_left > 0 else None, n_left,
-                 C.c_void_p(recv_right.data_ptr()) if n_right > 0 else None, n_right, layers, 7, 2 if density else 0)
+                 C.c_void_p(recv_right.data_ptr()) if n_right > 0 else None, n_right, layers, nl, 2 if density else 0)
         self._need_density = not density
         self._read_offsets(begin=False)
+        if not self._recut_due:
+            self.announce()
+
+    def announce(self):
         if getattr(self, "transport", None) is not None and hasattr(self.transport, "start_counts"):
             self.transport.start_counts(*self.next_counts())   # the next exchange's sizes are known now
 
+    # -- re-cut ("re-cut every K steps") ------------------------------------------------------
+    def local_histogram(self):
+        """Particles per GLOBAL x layer in this rank's owned layers (numpy int64 [nx_global]); synchronises."""
+        nx, H = self.nx_local, self.halo
+        off = np.asarray(self._offsets(list(range(nx + 1))), dtype=np.int64)
+        per_layer = np.diff(off)
+        hist = np.zeros(self.nx_global, dtype=np.int64)
+        g0 = self.x_lo - H                                     # global layer of local layer 0
+        for l in range(H, nx - H):
+            if 0 <= g0 + l < self.nx_global:
+                hist[g0 + l] = per_layer[l]
+        return hist
+
+    def plan_recut(self, hist):
+        """Every rank calls this with the same global histogram: new cuts, one layer at most from the old ones."""
+        new = plan_recut(self.cuts, hist, self.world, self.halo, width_cap=self.width_cap)
+        self._shift = (new[self.rank] - self.cuts[self.rank], new[self.rank + 1] - self.cuts[self.rank + 1])
+        self.cuts = list(new)
+
+    def recut_now(self):
+        """Collective: histogram all-reduce, plan, then announce the next exchange's (possibly deeper) counts."""
+        t = self.torch.from_numpy(self.local_histogram()).to(self.tdev)
+        self.transport.all_reduce_sum(t)
+        self.plan_recut(t.cpu().numpy())
+        self._recut_due = False
+        self.announce()
+
     def _layers(self):
         nx, H = self.nx_local, self.halo
-        return [H, 2 * H + 1, nx - 2 * H - 1, nx - H, nx, 2 * H, nx - 2 * H]   # [5], [6]: DFSPH velocity bands
+        # [5], [6]: DFSPH velocity bands; [7], [8]: the one-layer-deeper pack ranges of a re-cut
+        return [H, 2 * H + 1, nx - 2 * H - 1, nx - H, nx, 2 * H, nx - 2 * H, min(2 * H + 2, nx), max(nx - 2 * H - 2, 0)]
 
     def _read_offsets(self, begin):
         layers = self._layers()
+        nl = len(layers)
         if begin:
-            self.ps._call("sph_layer_offsets_begin", (C.c_int32 * 7)(*layers), 7)
-        out = (C.c_int32 * 7)()
-        self.ps._call("sph_layer_offsets_end", out, 7)
+            self.ps._call("sph_layer_offsets_begin", (C.c_int32 * nl)(*layers), nl)
+        out = (C.c_int32 * nl)()
+        self.ps._call("sph_layer_offsets_end", out, nl)
         o = list(out)
         self.ps._call("sph_truncate", o[4])               # drop the virtual cell
         self.off = o[:4]
+        self.off_ext = (o[7], o[8])
         self.owned_range = (o[0], o[3] - o[0])
         # DFSPH: ghost ranges and the owned bands that are the neighbours' ghosts (layers [H,2H) / [nx-2H,nx-H))
         self.ghost = {"L": (0, o[0]), "R": (o[3], o[4] - o[3])}
@@ -508,9 +611,14 @@ class SlabSolver:
         hm = self.host_ms
         if self.dfsph:
             for _ in range(n):
+                self._recut_due = self.recut_every > 0 and (self.steps_done + 1) % self.recut_every == 0
                 self._serve(self._dfsph_step_requests())
+                self.steps_done += 1
+                if self._recut_due:
+                    self.recut_now()
             return
         for _ in range(n):
+            self._recut_due = self.recut_every > 0 and (self.steps_done + 1) % self.recut_every == 0
             t0 = time.perf_counter()
             if self.dynamic_bodies:
                 self.phase_forces(pack=False)
@@ -522,6 +630,9 @@ class SlabSolver:
             rL, mL, rR, mR = self._exchange(*sent)
             t2 = time.perf_counter()
             self.phase_advance(rL, mL, rR, mR)
+            self.steps_done += 1
+            if self._recut_due:
+                self.recut_now()
             t3 = time.perf_counter()
             hm["forces_pack"] += (t1 - t0) * 1e3; hm["exchange"] += (t2 - t1) * 1e3; hm["advance"] += (t3 - t2) * 1e3
             hm["steps"] += 1
@@ -574,6 +685,15 @@ def run_local_slabs(solvers, n_steps, initialize=False):
         for s, r in zip(solvers, swap(sent)):
             s.phase_advance(*r, density=density)
 
+    def recut_if_due():
+        s0 = solvers[0]
+        for s in solvers:
+            s.steps_done += 1
+        if s0.recut_every > 0 and s0.steps_done % s0.recut_every == 0:
+            hist = sum(s.local_histogram() for s in solvers)
+            for s in solvers:
+                s.plan_recut(hist)
+
     if initialize:
         for s in solvers:
             s.solver._push()
@@ -614,6 +734,7 @@ def run_local_slabs(solvers, n_steps, initialize=False):
                     except StopIteration:
                         nxt.append(None)
                 reqs = None if all(x is None for x in nxt) else nxt
+            recut_if_due()
         return
     for _ in range(n_steps):
         if solvers[0].dynamic_bodies:
@@ -624,6 +745,7 @@ def run_local_slabs(solvers, n_steps, initialize=False):
         else:
             sent = [s.phase_forces() for s in solvers]
         exchange_and_advance(sent, True)
+        recut_if_due()
 
 
 def gather_by_pid(solvers, name, n_global):
@@ -671,7 +793,8 @@ def run_slab_bench(args, rank, world, local_rank):
     if dfsph:                                     # supplementary line, like bench.py --solver dfsph at N = 1
         sd["Configuration"]["simulationMethod"] = 4
         sd["Configuration"]["timeStepSize"] = 0.004
-    s = SlabSolver(sd, rank, world, device=local_rank, gather_impl=args.gather_impl, brick_shape=args.brick_shape)
+    s = SlabSolver(sd, rank, world, device=local_rank, gather_impl=args.gather_impl, brick_shape=args.brick_shape,
+                   recut_every=getattr(args, "recut_every", 0))
     s.attach(TorchTransport(torch.device("cuda", local_rank)))
     s.initialize()
     s.step(args.warmup)
@@ -730,7 +853,7 @@ def run_slab_bench(args, rank, world, local_rank):
         "config": {"workload": f"c3p_tiled_x{world}_{246 * world}x74x96", "particles": n_global,
                    "particles_owned_sum": int(own.item()), "cuts": s.cuts, "halo_layers": s.halo,
                    "sent_records_per_step": round(s.stats["sent"] / max(args.steps + args.warmup + 1, 1), 1),
-                   "backend": dist.get_backend(),
+                   "backend": dist.get_backend(), "recut_every": s.recut_every,
                    "rank0_host_ms_per_step": {k: round(v / max(host_ms["steps"], 1), 4)
                                               for k, v in host_ms.items() if k != "steps"},
                    "parallelism": f"x-slab x{world}, 1 exchange/step over "

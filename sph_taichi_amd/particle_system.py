@@ -21,8 +21,9 @@ from .field import DeviceField, HostScalar
 class ParticleSystem:
     def __init__(self, config: SimConfig, GGUI=False, device: int = 0, stream=None, scene_dir: str | None = None,
                  verbose: bool = False, slab: dict | None = None):
-        """`slab` (multi-GPU, no reference counterpart) = dict(x_lo, x_hi, halo, capacity): this
-        context owns the global cell layers [x_lo, x_hi) plus `halo` ghost layers on each side."""
+        """`slab` (multi-GPU, no reference counterpart) = dict(x_lo, x_hi, halo, capacity[, nx_slack]): this
+        context owns the global cell layers [x_lo, x_hi) plus `halo` ghost layers on each side; `nx_slack` more
+        layers are allocated so that a re-cut (`set_slab_window`) can widen the slab."""
         self.cfg = config
         self.GGUI = GGUI
         self.slab = slab
@@ -64,6 +65,8 @@ class ParticleSystem:
         # ---- device context (replaces the ti.field allocations of :91-145) ----
         self._lib = _lib.load()
         self._params = self._make_params(sc)
+        slack = int(slab.get("nx_slack", 0)) if slab is not None else 0
+        self._params.grid_num[0] += slack            # the allocation; the window is set right below
         ctx = C.c_void_p()
         stream_ptr = C.c_void_p(int(stream)) if stream else None
         rc = self._lib.sph_create(C.byref(self._params), int(device), stream_ptr, C.byref(ctx))
@@ -71,6 +74,9 @@ class ParticleSystem:
             msg = self._lib.sph_last_error(None)
             raise _lib.SphError(f"sph_create failed (rc={rc}): {msg.decode() if msg else ''}")
         self._ctx = ctx
+        if slack:
+            self._params.grid_num[0] -= slack
+            self._call("sph_slab_set_window", int(self._params.cell_origin[0]), int(self._params.grid_num[0]))
         n = self.count if slab is not None else (lambda: self.particle_max_num)
         F = _lib
         mk = lambda fid, dt, vec=0, w=True, name="": DeviceField(self, fid, dt, n, vec, w, name)
@@ -91,8 +97,8 @@ class ParticleSystem:
         if self.simulation_method == 4:                       # particle_system.py:115-117
             self.dfsph_factor = mk(F.F_DFSPH_FACTOR, np.float32, name="dfsph_factor")
             self.density_adv = mk(F.F_DENSITY_ADV, np.float32, name="density_adv")
-        G = int(np.prod(self._local_grid_num))
-        self.grid_particles_num = DeviceField(self, F.F_GRID_PARTICLES_NUM, np.int32, lambda: G, 0, False,
+        self.grid_particles_num = DeviceField(self, F.F_GRID_PARTICLES_NUM, np.int32,
+                                              lambda: int(np.prod(self._local_grid_num)), 0, False,
                                               "grid_particles_num")
         if self.num_rigid_bodies > 0:
             self.rigid_rest_cm = DeviceField(self, F.F_RIGID_REST_CM, np.float32, lambda: sc.n_objects, 3, True,
@@ -151,6 +157,16 @@ class ParticleSystem:
         kc = _scene.kernel_constants(g.support_radius, viscosity, g.dim)
         p.k_w, p.k_dw, p.visc_d_nu, p.visc_eps = kc["k_w"], kc["k_dw"], kc["visc_d_nu"], kc["visc_eps"]
         return p
+
+    def set_slab_window(self, x_lo, x_hi):
+        """Re-cut: this context now owns the global cell layers [x_lo, x_hi) (effective at the next sort)."""
+        sl = self.slab
+        nx = int(x_hi) - int(x_lo) + 2 * sl["halo"]
+        self._call("sph_slab_set_window", int(x_lo) - sl["halo"], nx)   # fails if wider than the allocation (nx_slack)
+        sl["x_lo"], sl["x_hi"] = int(x_lo), int(x_hi)
+        self._local_grid_num[0] = nx
+        self._params.grid_num[0] = nx
+        self._params.cell_origin[0] = sl["x_lo"] - sl["halo"]
 
     def _push_solver_params(self, solver):
         self._params = self._make_params(self._scene, solver)

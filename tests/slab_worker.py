@@ -53,7 +53,9 @@ def main():
         import json
         sd = json.load(open(sys.argv[6]))
         steps = int(sys.argv[7])
-        s = SlabSolver(sd, rank, world, device=0)
+        recut = int(sys.argv[8]) if len(sys.argv) > 8 else 0
+        cuts = json.loads(sys.argv[9]) if len(sys.argv) > 9 else None
+        s = SlabSolver(sd, rank, world, device=0, recut_every=recut, cuts=cuts)
         s.attach(TorchTransport(torch.device("cuda", 0)))
         s.initialize()
         s.step(steps)
@@ -62,7 +64,7 @@ def main():
         dist.all_gather_object(gathered, {k: v for k, v in o.items()})
         if rank == 0:
             pid = np.concatenate([g["pid"] for g in gathered])
-            np.savez(out, pid=pid, x=np.concatenate([g["x"] for g in gathered]),
+            np.savez(out, cuts=np.asarray(s.cuts), recuts=s.stats.get("recuts", 0), pid=pid, x=np.concatenate([g["x"] for g in gathered]),
                      v=np.concatenate([g["v"] for g in gathered]),
                      density=np.concatenate([g["density"] for g in gathered]))
         s.close()

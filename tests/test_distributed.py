@@ -114,6 +114,80 @@ def test_local_slabs_match_single_domain(world, which):
         s.close()
 
 
+def test_plan_recut_moves_one_layer_towards_balance():
+    from sph_taichi_amd.distributed import plan_recut
+    from sph_taichi_amd.scene import slab_cuts
+    hist = np.zeros(60, dtype=np.int64)
+    hist[4:28] = 100                                  # the fluid sits in the left half of the tank
+    for world, halo in ((2, 2), (3, 2), (4, 3)):
+        target = slab_cuts(hist, world, min_width=halo + 1)
+        cuts = [0] + [60 - (world - i) * (halo + 2) for i in range(1, world)] + [60]   # everything piled up on the right
+        for it in range(200):
+            new = plan_recut(cuts, hist, world, halo)
+            assert new[0] == 0 and new[-1] == 60
+            assert all(abs(a - b) <= 1 for a, b in zip(new, cuts))
+            assert all(new[i + 1] - new[i] >= halo + 1 for i in range(world))
+            for i in range(1, world):                 # a cut only moves into a slab that can pack one layer deeper
+                if new[i] > cuts[i]:
+                    assert cuts[i + 1] - cuts[i] >= halo + 2
+                if new[i] < cuts[i]:
+                    assert cuts[i] - cuts[i - 1] >= halo + 2
+            if new == cuts:
+                break
+            cuts = new
+        assert cuts == list(target), (cuts, target)
+    # the allocation caps a slab's width: slab 0 may not grow beyond 12 layers
+    cuts = [0, 10, 60]
+    hist2 = np.zeros(60, dtype=np.int64)
+    hist2[0:50] = 10
+    for _ in range(10):
+        cuts = plan_recut(cuts, hist2, 2, 2, width_cap=[12, 60])
+    assert cuts == [0, 12, 60]
+    # balanced already: nothing moves
+    assert plan_recut(list(slab_cuts(hist, 3, min_width=3)), hist, 3, 2) == list(slab_cuts(hist, 3, min_width=3))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["fluid-2", "fluid-3", "bodies-2", "dfsph-2"])
+def test_local_slabs_recut(case, tmp_path):
+    """Re-cut while running: the slabs start badly balanced, every other step each cut plane moves one
+    layer towards balance -- ownership changes hands through the running exchange, and the trajectory stays the
+    single-domain one."""
+    from sph_taichi_amd.distributed import SlabSolver, run_local_slabs, gather_by_pid, plan_recut
+    from sph_taichi_amd import scene as _scene
+    from sph_taichi_amd.config_builder import SimConfig
+    which, world = case.split("-")
+    world = int(world)
+    sd = {"fluid": lambda: _slab_scenes()[0], "dfsph": _dfsph_slab_scene,
+          "bodies": lambda: scenes.fluid_with_rigid_bodies(str(tmp_path / "cube.obj"), fluid_velocity=(0.8, -1.0, 0.0))}[which]()
+    steps = 24 if which != "dfsph" else 8
+    ref, n = _single_domain(sd, steps)
+    cfg = SimConfig(config=copy.deepcopy(sd))
+    hist = _scene.x_layer_histogram(cfg, base_dir=None)
+    halo = 3 if which == "bodies" else 2
+    balanced = list(_scene.slab_cuts(hist, world, min_width=halo + 1))
+    nx = len(hist)
+    filled = np.nonzero(hist)[0]
+    # skewed start: every interior cut 4 layers right of the balanced one (clipped so that every slab is valid)
+    cuts = [0] + [min(c + 4, nx - (world - i) * (halo + 1)) for i, c in enumerate(balanced[1:-1], 1)] + [nx]
+    assert cuts != balanced and filled.size > 0
+    solvers = [SlabSolver(sd, r, world, device=0, cuts=cuts, recut_every=2) for r in range(world)]
+    run_local_slabs(solvers, 1, initialize=True)
+    run_local_slabs(solvers, steps)
+    assert sum(s.stats.get("recuts", 0) for s in solvers) >= 2, "no cut moved"
+    assert all(s.cuts == solvers[0].cuts for s in solvers) and solvers[0].cuts != cuts
+    assert sum(abs(a - b) for a, b in zip(solvers[0].cuts, balanced)) < sum(abs(a - b) for a, b in zip(cuts, balanced))
+    for r, s in enumerate(solvers):
+        assert (s.x_lo, s.x_hi) == (s.cuts[r], s.cuts[r + 1])
+    x = gather_by_pid(solvers, "x", n)
+    assert not np.isnan(x).any(), "a particle is owned by no rank"
+    assert sum(s.owned_range[1] for s in solvers) == n, "a particle is owned by two ranks"
+    assert scenes.rel_l2(x, ref["x"]) <= (2e-6 if which != "dfsph" else 1e-4)
+    assert scenes.rel_l2(gather_by_pid(solvers, "v", n), ref["v"]) <= (2e-4 if which != "dfsph" else 1e-2)
+    for s in solvers:
+        s.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 3])
 def test_local_slabs_shape_matched_bodies(world, tmp_path):
@@ -220,17 +294,27 @@ def test_local_slabs_dfsph_with_dynamic_solids(world, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", ["fluid", "bodies", "dfsph"])
+@pytest.mark.parametrize("which", ["fluid", "bodies", "dfsph", "fluid_recut"])
 def test_two_gloo_ranks_on_one_gpu(tmp_path, which):
-    sd = {"fluid": lambda: _slab_scenes()[0], "dfsph": _dfsph_slab_scene,
+    sd = {"fluid": lambda: _slab_scenes()[0], "dfsph": _dfsph_slab_scene, "fluid_recut": lambda: _slab_scenes()[0],
           "bodies": lambda: scenes.fluid_with_rigid_bodies(str(tmp_path / "cube.obj"))}[which]()
     steps = 20 if which != "dfsph" else 8
     ref, n = _single_domain(sd, steps)
     scene_file = str(tmp_path / "scene.json")
     json.dump(sd, open(scene_file, "w"))
     out = str(tmp_path / "res.npz")
-    _spawn("slabs", 2, out, extra=(scene_file, str(steps)))
+    extra = (scene_file, str(steps))
+    if which == "fluid_recut":      # badly cut at the start, re-cut every other step (histogram all-reduce over gloo)
+        from sph_taichi_amd import scene as _scene
+        from sph_taichi_amd.config_builder import SimConfig
+        hist = _scene.x_layer_histogram(SimConfig(config=copy.deepcopy(sd)), base_dir=None)
+        bal = list(_scene.slab_cuts(hist, 2, min_width=3))
+        start = [0, min(bal[1] + 4, len(hist) - 3), len(hist)]
+        extra += ("2", json.dumps(start))
+    _spawn("slabs", 2, out, extra=extra)
     z = np.load(out)
+    if which == "fluid_recut":
+        assert int(z["recuts"]) >= 1 and abs(int(z["cuts"][1]) - bal[1]) < abs(start[1] - bal[1])
     assert np.array_equal(np.sort(z["pid"]), np.arange(n))
     x = np.empty_like(ref["x"])
     x[z["pid"]] = z["x"]

@@ -52,6 +52,15 @@ DevView sph_view(const SphContext* c) {
     return d;
 }
 
+// out[k] = number of records in local x layers [0, layers[k])  (the scanned cell table at a layer boundary)
+__global__ void k_read_layer_offsets(const int* __restrict__ cell_end, const int* __restrict__ layers, int n,
+                                     int per_layer, int* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int L = layers[k];
+    out[k] = L > 0 ? cell_end[(size_t)L * per_layer - 1] : 0;
+}
+
 struct CellIdx16 { int v[16]; };
 __global__ void k_read_cells(const int* __restrict__ cell_end, CellIdx16 ix, int* __restrict__ out) {
     const int k = threadIdx.x;
@@ -612,9 +621,21 @@ int32_t sph_layer_offsets(SphContext* c, const int32_t* layers, int32_t n, int32
     if (!layers || !out || n < 0) return SPH_E_INVALID;
     if (!c->have_prefix) return sph_fail(c, SPH_E_STATE, "sph_layer_offsets needs the prefix sum");
     const int per_layer = c->p.grid_num[1] * c->p.grid_num[2];
+    for (int k = 0; k < n; ++k)
+        if (layers[k] < 0 || layers[k] > c->p.grid_num[0]) return sph_fail(c, SPH_E_INVALID, "layer out of range");
+    if (n > 8 && (size_t)n * 8 <= c->stage_bytes) {
+        // many layers (the per-layer histogram of a re-cut): list up, one kernel, offsets back -- not n copies
+        int* dl = (int*)c->stage;
+        int* dout = dl + n;
+        SPH_HIP(c, hipMemcpyAsync(dl, layers, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_read_layer_offsets, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->cell_end, dl, n, per_layer, dout);
+        SPH_LAUNCH_CHECK(c);
+        SPH_HIP(c, hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        SPH_HIP(c, hipStreamSynchronize(c->stream));
+        return 0;
+    }
     for (int k = 0; k < n; ++k) {
         const int L = layers[k];
-        if (L < 0 || L > c->p.grid_num[0]) return sph_fail(c, SPH_E_INVALID, "layer out of range");
         if (L == 0) out[k] = 0;
         else SPH_HIP(c, hipMemcpyAsync(&out[k], c->cell_end + (size_t)L * per_layer - 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     }

@@ -114,21 +114,32 @@ class TorchTransport:
         works = dist.batch_isend_irecv(ops) if ops else []
         self._pending = (works, out, cin, (n_left, n_right))
 
+    def resolve_counts(self):
+        """Wait for the counts posted by start_counts and read them (a device-to-host copy each on RCCL).  Called
+        while the host would otherwise sit waiting for the packers, so that it is off the exchange's critical path."""
+        if getattr(self, "_pending", None) is None:
+            return
+        works, _out, cnt_in, announced = self._pending
+        self._pending = None
+        for w in works:
+            w.wait()
+        self._resolved = ({p: int(cnt_in[p].item()) for p in cnt_in}, announced)
+
     def exchange(self, send_left, n_left, send_right, n_right, alloc):
         """send_* : uint8 device tensors (or None at the domain ends) holding n_* records.
         Returns (recv_left, n, recv_right, n)."""
         torch, dist = self.torch, self.dist
         left, right = self._neighbours()
-        # 1) counts: posted ahead by start_counts, or exchanged now (first call)
-        if getattr(self, "_pending", None) is None:
-            self.start_counts(n_left, n_right)
-        works, _out, cnt_in, announced = self._pending
-        self._pending = None
+        # 1) counts: posted ahead by start_counts (and usually read already, see resolve_counts), or exchanged
+        #    now (first call)
+        if getattr(self, "_resolved", None) is None:
+            if getattr(self, "_pending", None) is None:
+                self.start_counts(n_left, n_right)
+            self.resolve_counts()
+        n_in, announced = self._resolved
+        self._resolved = None
         if announced != (n_left, n_right):
             raise RuntimeError(f"rank {self.rank}: announced counts {announced} != sent counts {(n_left, n_right)}")
-        for w in works:
-            w.wait()
-        n_in = {p: int(cnt_in[p].item()) for p in cnt_in}
         # 2) payload
         bufs = {}
         ops = []
@@ -384,6 +395,8 @@ class SlabSolver:
         ps._call("sph_slab_forces", bl[0], bl[1], br[0], br[1],
                  fL, nL, C.c_void_p(self.send_buf["L"].data_ptr()),
                  fR, nR, C.c_void_p(self.send_buf["R"].data_ptr()))
+        if getattr(self, "transport", None) is not None and hasattr(self.transport, "resolve_counts"):
+            self.transport.resolve_counts()        # the neighbours' counts, read while the packers are still queued
         ps._call("sph_slab_wait_pack")
         self.stats["sent"] += nL + nR
         return self.send_buf["L"], nL, self.send_buf["R"], nR

@@ -189,6 +189,20 @@ def test_local_slabs_recut(case, tmp_path):
 
 
 @pytest.mark.gpu
+def test_slab_window_is_bounded_by_the_allocation():
+    from sph_taichi_amd.distributed import SlabSolver
+    from sph_taichi_amd import _lib
+    s = SlabSolver(_slab_scenes()[0], 0, 2, device=0, recut_every=5, nx_slack=2)
+    w = s.x_hi - s.x_lo
+    s.ps.set_slab_window(s.x_lo, s.x_hi + 2)                  # the slack
+    assert s.ps._local_grid_num[0] == w + 2 + 2 * s.halo
+    with pytest.raises(_lib.SphError, match="allocation"):
+        s.ps.set_slab_window(s.x_lo, s.x_hi + 3)
+    assert s.ps._local_grid_num[0] == w + 2 + 2 * s.halo      # a refused window changes nothing
+    s.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 3])
 def test_local_slabs_shape_matched_bodies(world, tmp_path):
     """Dynamic RigidBodies straddling the cut planes: per-rank sums + all-reduce reproduce the single-domain

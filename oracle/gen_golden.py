@@ -152,6 +152,21 @@ def main():
         d["Configuration"]["timeStepSize"] = 0.002
     jobs["ref_dfsph_wall"] = (d1, 8)
     jobs["ref_dfsph_rigid"] = (d2, 8)
+    # two fluids of different density (particle_system.py:231 m = m_V0 * density: different particle masses) running
+    # into each other above a static slab: the general (non-uniform-mass) force sweep, WCSPH.py:47-112
+    d5 = scenes.fluid_with_rigid_blocks(fluid_counts=(6, 6, 5), static_counts=(16, 2, 9), dyn_counts=(3, 3, 3))
+    f0 = d5["FluidBlocks"][0]
+    f0["velocity"] = [1.5, -0.5, 0.0]
+    s1 = (f0["start"][0] + 6 * 0.02 + 0.03, f0["start"][1], f0["start"][2])
+    f1 = copy.deepcopy(f0)
+    f1.update(objectId=3, start=list(s1), end=scenes.lattice_end(s1, (5, 6, 5)), density=600.0, velocity=[-1.5, -0.5, 0.0],
+              color=[200, 100, 50])
+    d5["FluidBlocks"].append(f1)
+    jobs["ref_two_fluids"] = (d5, 8)
+    d6 = copy.deepcopy(d5)                                   # ... and under DFSPH (the general *_ITER sweeps)
+    d6["Configuration"]["simulationMethod"] = 4
+    d6["Configuration"]["timeStepSize"] = 0.002
+    jobs["ref_dfsph_two_fluids"] = (d6, 6)
     only = sys.argv[1:]
     for name, (sd, steps) in jobs.items():
         if only and name not in only:

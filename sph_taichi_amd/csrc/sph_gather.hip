@@ -698,13 +698,25 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
 
     // round-0 target loads are issued here, together with the staging loads below, so that their latency is
     // not a third dependent phase after the staging barrier
+    // Lane -> target number.  The filter's ds_read_b128 is served in four fixed groups of 16 lanes
+    // ({0-3,12-15,20-27}, {4-11,16-19,28-31}, same +32); with targets in natural order every group holds lanes of
+    // all four z-cells of a column, whose runs start 8 records = 128 B = half a bank row apart at rest: cells 0/2
+    // and 1/3 sit on the same banks (2-way conflict on every filter read).  Within each full block of 32 targets
+    // the lanes are therefore assigned so that a group only holds cells {0,1} or {2,3}.  The same cache lines are
+    // touched by the wave's global accesses either way.
+    auto tmap = [&](int tn) -> int {
+        if (mode_reads_list<MODE>() || (tn | 31) >= T) return tn;
+        const int l = tn & 31;
+        return (tn & ~31) | (int)(((0x73261540u >> ((l >> 2) * 4)) & 7u) << 2) | (l & 3);
+    };
     int col_0 = 0, gi_0 = 0, key_0 = 0;
     float4 Ai_0 = make_float4(0.f, 0.f, 0.f, 0.f), Bi_0 = Ai_0, Ei_0 = Ai_0;
     if (tid < T) {
+        const int tq = tmap(tid);
 #pragma unroll
         for (int step = 16; step > 0; step >>= 1)
-            if (sTOff[col_0 + step] <= tid) col_0 += step;
-        gi_0 = sTG[col_0] + (tid - sTOff[col_0]);
+            if (sTOff[col_0 + step] <= tq) col_0 += step;
+        gi_0 = sTG[col_0] + (tq - sTOff[col_0]);
         Ai_0 = d.xm[gi_0];
         Bi_0 = d.vf[gi_0];
         Ei_0 = target_load_E<MODE>(d, gi_0);
@@ -744,11 +756,12 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
         int col = col_0, gi = gi_0, key_i = key_0;
         float4 Ai = Ai_0, Bi = Bi_0, Ei = Ei_0;
         if (tn != tid) {  // later rounds (bricks with more than 256 targets)
+            const int tq = tmap(tn);
             col = 0;
 #pragma unroll
             for (int step = 16; step > 0; step >>= 1)
-                if (sTOff[col + step] <= tn) col += step;
-            gi = sTG[col] + (tn - sTOff[col]);
+                if (sTOff[col + step] <= tq) col += step;
+            gi = sTG[col] + (tq - sTOff[col]);
             Ai = d.xm[gi];
             Bi = d.vf[gi];
             Ei = target_load_E<MODE>(d, gi);

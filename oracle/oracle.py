@@ -12,7 +12,6 @@ scalars [N], ints i32.
 from __future__ import annotations
 
 import ctypes as C
-import math
 import os
 import subprocess
 

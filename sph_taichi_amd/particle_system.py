@@ -9,7 +9,6 @@ neighbour-structure kernels update_grid_id / prefix sum / counting_sort.
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import numpy as np
 

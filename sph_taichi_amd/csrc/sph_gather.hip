@@ -596,34 +596,42 @@ struct BrickCfg {
 // per-XCD chunks are chunks of WORK: a fluid that fills a corner of the tank still loads all 8 XCDs evenly.
 template <class CFG>
 __global__ __launch_bounds__(TPB) void k_brick_list(DevView d, int nbx, int nby, int nbz, int* __restrict__ list,
-                                                    int* __restrict__ count) {
+                                                    int* __restrict__ count, int list_cap) {
+    // Two lists in one array: bricks with many targets from the front (count[0]), light ones -- the partly filled
+    // bricks along the fluid's surface and the tank walls -- from the back (count[1]).  The gather kernel starts
+    // the heavy ones first, so that the launch drains on short jobs instead of on whatever came last.
     const int b = blockIdx.x * TPB + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    bool has = false;
+    int tgt = 0;
     if (b < nbx * nby * nbz) {
         const int bzi = b % nbz, byi = (b / nbz) % nby, bxi = b / (nbz * nby);
         const int cx0 = bxi * CFG::BX, cy0 = byi * CFG::BY, cz0 = bzi * CFG::BZ;
         const int cx1 = min(cx0 + CFG::BX, d.nx), cy1 = min(cy0 + CFG::BY, d.ny), cz1 = min(cz0 + CFG::BZ, d.nz);
-        for (int ix = cx0; ix < cx1 && !has; ++ix) {
+        for (int ix = cx0; ix < cx1; ++ix) {
             if (!((ix >= d.tgt_lo && ix < d.tgt_hi) || (ix >= d.tgt_lo2 && ix < d.tgt_hi2))) continue;
-            for (int iy = cy0; iy < cy1 && !has; ++iy) {
+            for (int iy = cy0; iy < cy1; ++iy) {
                 const int lo = sph_flatten(d, ix, iy, cz0), hi = sph_flatten(d, ix, iy, cz1 - 1);
-                has = d.cell_end[hi] > (lo > 0 ? d.cell_end[lo - 1] : 0);
+                tgt += d.cell_end[hi] - (lo > 0 ? d.cell_end[lo - 1] : 0);
             }
         }
     }
-    const unsigned long long m = __ballot(has);
-    int base = 0;
-    if (lane == 0 && m) base = atomicAdd(count, __popcll(m));
-    base = __shfl(base, 0, 64);
-    if (has) list[base + __popcll(m & ((1ull << lane) - 1ull))] = b;
+    const bool heavy = tgt >= SPH_BRICK_HEAVY, light = tgt > 0 && !heavy;
+    const unsigned long long mh = __ballot(heavy), ml = __ballot(light);
+    int baseh = 0, basel = 0;
+    if (lane == 0 && mh) baseh = atomicAdd(&count[0], __popcll(mh));
+    if (lane == 0 && ml) basel = atomicAdd(&count[1], __popcll(ml));
+    baseh = __shfl(baseh, 0, 64);
+    basel = __shfl(basel, 0, 64);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (heavy) list[baseh + __popcll(mh & below)] = b;
+    if (light) list[list_cap - 1 - (basel + __popcll(ml & below))] = b;
 }
 
 template <int MODE, class CFG>
 __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nbz, const int* __restrict__ brick_list,
                                                       const int* __restrict__ brick_count,
                                                       unsigned short* __restrict__ glist,
-                                                      unsigned char* __restrict__ gcnt, int cap) {
+                                                      unsigned char* __restrict__ gcnt, int cap, int list_cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool HAS_W = !mode_reads_list<MODE>();
     float4* sQ = reinterpret_cast<float4*>(smem + CFG::OFF_Q);
@@ -644,12 +652,20 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
     // XCD x takes the x-th eighth of the list, so neighbouring bricks share that XCD's L2 and -- because the list
     // holds work, not space -- all 8 XCDs are loaded evenly however the fluid sits in the tank.  The grid is sized
     // for the worst case (every brick non-empty); surplus blocks leave here.
-    const int nb = *brick_count;
-    const int chunk = (nb + 7) >> 3;
-    const int kb = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= chunk || kb >= nb) return;
+    const int nbh = brick_count[0], nbl = brick_count[1];
+    const int chunkh = (nbh + 7) >> 3, chunkl = (nbl + 7) >> 3;
+    const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
+    int brick;
+    if (slot < chunkh) {  // heavy bricks first (blocks are dispatched in blockIdx order) ...
+        const int kb = xcd * chunkh + slot;
+        if (kb >= nbh) return;
+        brick = brick_list[kb];
+    } else {  // ... the light ones fill the tail
+        const int kb = xcd * chunkl + (slot - chunkh);
+        if (slot - chunkh >= chunkl || kb >= nbl) return;
+        brick = brick_list[list_cap - 1 - kb];
+    }
     {
-    const int brick = brick_list[kb];
     const int bzi = brick % nbz;
     const int byi = (brick / nbz) % nby;
     const int bxi = brick / (nbz * nby);
@@ -969,7 +985,7 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         attr_set[dev] = true;
     }
-    const int grid = (nbricks + 7) / 8 * 8;
+    const int grid = (nbricks + 7) / 8 * 8 + 8;  // per XCD: ceil(heavy / 8) + ceil(light / 8) <= ceil(nbricks / 8) + 1 slots
     // the list of non-empty bricks depends only on the order and the target layers: every sweep of a step that
     // shares them (density + force; all ~30 sweeps of a DFSPH step) reuses it
     const int key[5] = {CFG::BX * 100 + CFG::BY * 10 + CFG::BZ, d.tgt_lo, d.tgt_hi, d.tgt_lo2, d.tgt_hi2};
@@ -977,9 +993,9 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
     int* blist = c->use_side ? c->brick_list2 : c->brick_list;
     int* bcount = c->use_side ? c->brick_count2 : c->brick_count;
     if (c->use_side || !c->bricks_valid || memcmp(key, c->bricks_key, sizeof(key)) != 0) {
-        if (c->use_side || !c->brick_count_zero) SPH_HIP(c, hipMemsetAsync(bcount, 0, sizeof(int), st));
+        if (c->use_side || !c->brick_count_zero) SPH_HIP(c, hipMemsetAsync(bcount, 0, 2 * sizeof(int), st));
         if (!c->use_side) c->brick_count_zero = false;
-        hipLaunchKernelGGL((k_brick_list<CFG>), dim3((nbricks + TPB - 1) / TPB), dim3(TPB), 0, st, d, nbx, nby, nbz, blist, bcount);
+        hipLaunchKernelGGL((k_brick_list<CFG>), dim3((nbricks + TPB - 1) / TPB), dim3(TPB), 0, st, d, nbx, nby, nbz, blist, bcount, c->brick_cap);
         SPH_LAUNCH_CHECK(c);
         if (!c->use_side) {  // (the side stream's list is private to that launch and never cached)
             memcpy(c->bricks_key, key, sizeof(key));
@@ -987,7 +1003,7 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
         }
     }
     hipLaunchKernelGGL((k_gather_brick<MODE, CFG>), dim3(grid), dim3(TPB), bytes, st, d, nby, nbz, blist, bcount, c->glist,
-                       c->gcnt, c->cap);
+                       c->gcnt, c->cap, c->brick_cap);
     SPH_LAUNCH_CHECK(c);
     return 0;
 }

@@ -148,6 +148,7 @@ struct SphContext {
 DevView sph_view(const SphContext* c);
 static inline hipStream_t sph_stream(const SphContext* c) { return c->use_side ? c->side : c->stream; }
 // particle positions / order / flags changed: neighbour lists and the non-empty-brick list are stale
+#define SPH_BRICK_HEAVY 160  // targets from which a brick counts as heavy (a full 4x2x4 brick at rest has 256)
 static inline void sph_invalidate_lists(SphContext* c) { c->lists_valid = false; c->bricks_valid = false; c->stg_kind = 0; c->k_kind = 0; }
 int sph_fail(SphContext* c, int code, const char* what);
 

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(TPB) void k_stable_scatter(DevView d, const int* __
                                                         int* __restrict__ dyn_count, int4* __restrict__ zero_dst,
                                                         int zero_n4, int* __restrict__ brick_count) {
     const int s = blockIdx.x * TPB + threadIdx.x;
-    if (s == 0) *brick_count = 0;  // for the first brick-list build on the new order
+    if (s == 0) brick_count[0] = brick_count[1] = 0;  // (heavy, light) for the first brick-list build on the new order
     // the OTHER cell array (the previous step's, dead by now) is zeroed here for the next histogram: 2 MB of stores in
     // a 180 MB kernel instead of a memset launch of its own (~10 us per step)
     for (int z = s; z < zero_n4; z += gridDim.x * TPB) zero_dst[z] = make_int4(0, 0, 0, 0);

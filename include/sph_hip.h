@@ -187,6 +187,22 @@ int32_t sph_sync(SphContext* ctx);
 int32_t sph_get_timings(SphContext* ctx, SphTimings* out);
 int32_t sph_reset_timings(SphContext* ctx);
 
+/* Neighbourhood statistics of the LAST density sweep of the LDS-brick path (no reference counterpart; the
+ * reference's for_all_neighbors, particle_system.py:378-385, has no capacity limits to report on).  They say how
+ * far a flow state is from the rest lattice and whether any target left the fast path.  Synchronises. */
+typedef struct SphStats {
+    int64_t targets;               /* fluid particles that gathered */
+    int64_t list_entries;          /* sum of their neighbour-list lengths (superset filter: includes the particle
+                                      itself and pairs within 1e-4 h beyond h) */
+    int32_t max_list;              /* longest list */
+    int32_t list_overflow_targets; /* lists longer than the hand-off capacity (63): the force sweep walks the cells */
+    int32_t lds_overflow_targets;  /* targets of bricks whose shell did not fit the LDS tile: both sweeps walk the cells */
+    int32_t max_cell_occupancy;    /* particles in the fullest cell */
+    int32_t nonempty_cells;
+    int32_t reserved_;
+} SphStats;
+int32_t sph_get_stats(SphContext* ctx, SphStats* out);
+
 /* --- multi-GPU slab support (no reference counterpart) -------------
  * Cells are flattened x-slowest (particle_system.py:294), so after the sort every
  * set of x-layers is ONE contiguous index range.  A slab rank exchanges such ranges

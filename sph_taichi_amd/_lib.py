@@ -33,6 +33,12 @@ class SphTimings(C.Structure):
                 ("steps", C.c_int64)]
 
 
+class SphStats(C.Structure):
+    _fields_ = [("targets", C.c_int64), ("list_entries", C.c_int64), ("max_list", C.c_int32),
+                ("list_overflow_targets", C.c_int32), ("lds_overflow_targets", C.c_int32),
+                ("max_cell_occupancy", C.c_int32), ("nonempty_cells", C.c_int32), ("reserved_", C.c_int32)]
+
+
 class SphDfsphParams(C.Structure):
     _fields_ = [("enable_divergence_solver", C.c_int32), ("m_max_iterations_v", C.c_int32),
                 ("m_max_iterations", C.c_int32), ("fluid_particle_num", C.c_int32), ("m_eps", C.c_float),
@@ -86,6 +92,7 @@ SYMBOLS = [
     ("sph_sync", C.c_int32, [_ctx]),
     ("sph_get_timings", C.c_int32, [_ctx, C.POINTER(SphTimings)]),
     ("sph_reset_timings", C.c_int32, [_ctx]),
+    ("sph_get_stats", C.c_int32, [_ctx, C.POINTER(SphStats)]),
     ("sph_get_particle_count", C.c_int32, [_ctx, C.POINTER(C.c_int32)]),
     ("sph_layer_offsets", C.c_int32, [_ctx, C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]),
     ("sph_layer_offsets_begin", C.c_int32, [_ctx, C.POINTER(C.c_int32), C.c_int32]),

@@ -29,6 +29,7 @@ DevView sph_view(const SphContext* c) {
     d.grid_size = p.grid_size; d.h = p.support_radius; d.inv_h = 1.0f / p.support_radius;
     d.d2 = p.particle_diameter * p.particle_diameter;  // WCSPH.py:96
     d.m_V0 = p.m_V0; d.rho0 = p.density_0; d.stiffness = p.stiffness; d.exponent = p.exponent;
+    d.exp_int = (p.exponent >= 1.0f && p.exponent <= 32.0f && p.exponent == (float)(int)p.exponent) ? (int)p.exponent : 0;
     d.sigma = p.surface_tension; d.dt = p.dt;
     d.gx = p.g[0]; d.gy = p.g[1]; d.gz = p.g[2];
     d.pad = p.padding;
@@ -736,6 +737,13 @@ int32_t sph_get_timings(SphContext* c, SphTimings* out) {
     if (rc) return rc;
     *out = c->tm;
     return 0;
+}
+
+int32_t sph_get_stats(SphContext* c, SphStats* out) {
+    ENTER(c);
+    if (!out) return SPH_E_INVALID;
+    if (!c->have_prefix) return sph_fail(c, SPH_E_STATE, "sph_get_stats needs a sorted state (run a step first)");
+    return sphk_stats(c, out);
 }
 
 int32_t sph_reset_timings(SphContext* c) {

@@ -344,11 +344,11 @@ __device__ __forceinline__ void target_finish(const DevView& d, Target& t, int i
         if (gathered) {
             const float rho_raw = (t.self_in_sum ? t.s0 : t.mV * d.w_zero + t.s0) * d.rho0;  // WCSPH.py:39-43
             const float rho = fmaxf(rho_raw, d.rho0);                 // WCSPH.py:75
-            // WCSPH.py:76 ti.pow(rho / rho0, exponent) as exp2(exponent * log2(x)) on the hardware transcendentals
-            // (~1e-6 relative on p; exactly 0 at rho = rho0, where most of a resting fluid sits after the clamp) and
-            // reciprocals instead of IEEE divisions: libm powf + three divides were ~130 instructions per particle
-            const float xr = rho * sph_rcp(d.rho0);
-            const float p = d.stiffness * (__builtin_amdgcn_exp2f(d.exponent * __builtin_amdgcn_logf(xr)) - 1.0f);
+            // WCSPH.py:76 ti.pow(rho / rho0, exponent): integer exponents by multiplication (sph_tait_pow); the ratio is
+            // the IEEE quotient (once per particle; its error is amplified by stiffness * exponent), the later
+            // divisions are reciprocals.  Exactly 0 at rho = rho0, where most of a resting fluid sits after the clamp.
+            const float xr = rho / d.rho0;
+            const float p = d.stiffness * (sph_tait_pow<true>(d, xr) - 1.0f);
             e = make_float4(p * sph_rcp(rho * rho), aux.x * sph_rcp(rho_raw), aux.x, rho);
             aux.y = rho; aux.z = p;
             d.aux[i] = aux;
@@ -555,7 +555,8 @@ __global__ __launch_bounds__(TPB) void k_gather_bvol_split(DevView d, const int*
 // In the fused step the density sweep writes each target's list to HBM
 // (glist[k*cap + i], gcnt[i]) and the force sweep -- same positions, same
 // brick layout -- reads it back instead of filtering again.
-#define SPH_CNT_WALK 255  // gcnt sentinel: this target must take the exact global cell walk
+#define SPH_CNT_WALK 255  // gcnt sentinel: this target must take the exact global cell walk (its brick's shell overflowed the LDS tile)
+#define SPH_CNT_LIST_OVF 254  // same consequence, other cause: the target's own list outgrew LISTCAP
 
 template <int MODE>
 __host__ __device__ constexpr bool mode_writes_list() { return MODE == GM_DENSITY_EOS || MODE == GM_DF_DENSITY; }
@@ -586,7 +587,7 @@ struct BrickCfg {
     static constexpr int bytes(bool has_w) { return off_toff(has_w) + 80 * 4; }
     static_assert(NCOL <= 32, "column id must fit 5 bits of a list entry");
     static_assert(CAP <= 2048, "LDS slot must fit 11 bits of a list entry");
-    static_assert(LISTCAP < SPH_CNT_WALK && LISTCAP <= SPH_GLIST_ROWS, "gcnt is a byte; glist has SPH_GLIST_ROWS rows");
+    static_assert(LISTCAP < SPH_CNT_LIST_OVF && LISTCAP <= SPH_GLIST_ROWS, "gcnt is a byte; glist has SPH_GLIST_ROWS rows");
     static_assert(bytes(true) <= 40960, "filtering sweeps: at least four workgroups per CU (160 KiB LDS)");
     static_assert(bytes(false) <= 32768, "force sweep: five workgroups per CU");
 };
@@ -869,12 +870,12 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
             // lives there does not meet itself in the list and keeps the explicit self term)
             if (mode_inline_physics<MODE>()) t.self_in_sum = key_i != 0;
             else if (list_ovf) walk = true;
-            if (mode_writes_list<MODE>()) gcnt[gi] = (unsigned char)((walk || list_ovf) ? SPH_CNT_WALK : cnt);
+            if (mode_writes_list<MODE>()) gcnt[gi] = (unsigned char)(walk ? SPH_CNT_WALK : list_ovf ? SPH_CNT_LIST_OVF : cnt);
             __threadfence_block();  // this lane re-reads its own entries below
         }
         if (mode_reads_list<MODE>() && g && !overflow) {
             cnt = gcnt[gi];
-            if (cnt == SPH_CNT_WALK) { walk = true; cnt = 0; }
+            if (cnt >= SPH_CNT_LIST_OVF) { walk = true; cnt = 0; }
         }
         if (mode_writes_list<MODE>() && g && overflow) gcnt[gi] = (unsigned char)SPH_CNT_WALK;
         if (g && !walk && !(d.ablate & 1) && !mode_inline_physics<MODE>()) {
@@ -941,7 +942,7 @@ __global__ __launch_bounds__(TPB) void k_eos(DevView d) {
     if (!sph_is_fluid(__float_as_int(d.vf[i].w))) return;
     float4 aux = d.aux[i];
     aux.y = fmaxf(aux.y, d.rho0);
-    aux.z = d.stiffness * (powf(aux.y / d.rho0, d.exponent) - 1.0f);
+    aux.z = d.stiffness * (sph_tait_pow<false>(d, aux.y / d.rho0) - 1.0f);
     d.aux[i] = aux;
 }
 
@@ -1090,6 +1091,61 @@ int sphk_gather(SphContext* c, int mode) {
         case GM_DF_NONPRESSURE: return launch_df<GM_DF_NONPRESSURE>(c);
     }
     return sph_fail(c, SPH_E_INVALID, "unknown gather mode");
+}
+
+// sph_get_stats: what the last density sweep left in gcnt, plus the cell histogram
+__global__ __launch_bounds__(TPB) void k_stats(DevView d, const unsigned char* __restrict__ gcnt, unsigned long long* __restrict__ out) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int tgt = 0, len = 0, lovf = 0, sovf = 0, occ = 0, ne = 0;
+    if (i < d.N && sph_is_fluid(__float_as_int(d.vf[i].w))) {
+        const int c = gcnt[i];
+        tgt = 1;
+        if (c == SPH_CNT_WALK) sovf = 1;
+        else if (c == SPH_CNT_LIST_OVF) lovf = 1;
+        else len = c;
+    }
+    if (i < d.G) {
+        occ = d.cell_end[i] - (i > 0 ? d.cell_end[i - 1] : 0);
+        ne = occ > 0;
+    }
+    int mx = len;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        tgt += __shfl_xor(tgt, off, 64); lovf += __shfl_xor(lovf, off, 64); sovf += __shfl_xor(sovf, off, 64);
+        ne += __shfl_xor(ne, off, 64);
+        mx = max(mx, __shfl_xor(mx, off, 64)); occ = max(occ, __shfl_xor(occ, off, 64));
+    }
+    int sum = len;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) {
+        if (tgt) atomicAdd(&out[0], (unsigned long long)tgt);
+        if (sum) atomicAdd(&out[1], (unsigned long long)sum);
+        if (mx) atomicMax(&out[2], (unsigned long long)mx);
+        if (lovf) atomicAdd(&out[3], (unsigned long long)lovf);
+        if (sovf) atomicAdd(&out[4], (unsigned long long)sovf);
+        if (occ) atomicMax(&out[5], (unsigned long long)occ);
+        if (ne) atomicAdd(&out[6], (unsigned long long)ne);
+    }
+}
+
+int sphk_stats(SphContext* c, SphStats* out) {
+    memset(out, 0, sizeof(*out));
+    if (c->N <= 0) return 0;
+    DevView d = sph_view(c);
+    unsigned long long* dev = reinterpret_cast<unsigned long long*>(c->stage);  // 7 words of the staging buffer
+    unsigned long long h[7];
+    SPH_HIP(c, hipMemsetAsync(dev, 0, sizeof(h), c->stream));
+    const int n = max(c->N, c->G);
+    hipLaunchKernelGGL(k_stats, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, c->gcnt, dev);
+    SPH_LAUNCH_CHECK(c);
+    SPH_HIP(c, hipMemcpyAsync(h, dev, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    SPH_HIP(c, hipStreamSynchronize(c->stream));
+    out->targets = (int64_t)h[0]; out->list_entries = (int64_t)h[1]; out->max_list = (int32_t)h[2];
+    out->list_overflow_targets = (int32_t)h[3]; out->lds_overflow_targets = (int32_t)h[4];
+    out->max_cell_occupancy = (int32_t)h[5]; out->nonempty_cells = (int32_t)h[6];
+    return 0;
 }
 
 int sphk_eos(SphContext* c) {

@@ -36,6 +36,7 @@ struct DevView {
     int tgt_lo2, tgt_hi2;  // ... plus an optional second range (slab mode: both boundary sets in one launch)
     int sort_by_pid;   // intra-cell order by persistent id (SPH_OPT_SORT_BY_PID)
     int drop_outside;  // slab mode: x layer outside the local grid -> virtual cell G
+    int exp_int;     // Tait exponent as a small integer (1..32) when it is one, else 0 (WCSPH.py:76)
     int ablate;      // debug: bit0 skip phase 2, bit1 skip list write-out, bit2 skip phase 1 (profiling only)
     float grid_size, h, inv_h, d2, m_V0, rho0, stiffness, exponent, sigma, dt;
     float gx, gy, gz;
@@ -175,6 +176,7 @@ int sphk_gather(SphContext* c, int mode);
 int sphk_gather_layers(SphContext* c, int mode, int lo, int hi, int lo2, int hi2);  // brick sweep, targets in x layers [lo,hi) u [lo2,hi2)
 int sphk_pack_advected(SphContext* c, int first, int count, void* dst);
 int sphk_eos(SphContext* c);
+int sphk_stats(SphContext* c, SphStats* out);  // synchronises
 int sphk_check_uniform_fluid(SphContext* c);  // sets uniform_state / m_uniform (synchronises)
 int sphk_df_density_error(SphContext* c, float offset, float* out_host);
 int sphk_df_density_error_range(SphContext* c, float offset, int first, int count, double* out_host);
@@ -245,6 +247,23 @@ __device__ __forceinline__ int sph_wave_inclusive_scan(int v, int lane) {
         if (lane >= off) v += n;
     }
     return v;
+}
+
+// WCSPH.py:76 ti.pow(x, exponent).  Every scene of the reference has an integer exponent (7): x^7 is four
+// multiplies (~2 ulp) -- cheaper and an order of magnitude more accurate than exp2(e * log2 x) on the hardware
+// transcendentals, whose error is amplified by stiffness * (x^e - 1) at x ~ 1.  exp_int is a kernel argument, so the
+// loop is scalar control flow.  Non-integer exponents keep the transcendental form (FAST) or libm's powf.
+template <bool FAST>
+__device__ __forceinline__ float sph_tait_pow(const DevView& d, float x) {
+    if (d.exp_int > 0) {
+        float r = 1.0f, b = x;
+        for (int e = d.exp_int; e; e >>= 1) {
+            if (e & 1) r *= b;
+            b *= b;
+        }
+        return r;
+    }
+    return FAST ? __builtin_amdgcn_exp2f(d.exponent * __builtin_amdgcn_logf(x)) : powf(x, d.exponent);
 }
 
 // sph_base.py:149-179 enforce_boundary_3D body for one particle

@@ -126,8 +126,15 @@ enum SphOption {
     SPH_OPT_SORT_BY_PID = 9    /* 1 = inside a cell, order by persistent id instead of by previous index.  The reference
                                   order (previous index) is kept on a single GPU; slab ranks running DFSPH need an order
                                   that the owner of a boundary band and the neighbour holding it as ghosts agree on, so
-                                  that ghost velocities can be refreshed record for record */
+                                  that ghost velocities can be refreshed record for record */,
+    SPH_OPT_KERNEL_VARIANT = 10 /* A/B switch for the brick sweeps of the fused WCSPH step (default brick shape): bit mask of
+                                  SPH_VAR_* below.  Every combination computes the same sums (list order and rounding
+                                  apart); -1 = the library's default */
 };
+#define SPH_VAR_PAD 1      /* candidate filter in whole groups of 8 (reads past a run's end masked off), no one-at-a-time tail */
+#define SPH_VAR_2PHASE 2   /* density: pair terms in a second loop over the lane's own list instead of inside the emission loop */
+#define SPH_VAR_MICRO 4    /* emission loop: constants in VGPRs, range-checked buffer stores (no branch, no 64-bit address) */
+#define SPH_VAR_FORCE_BF 8 /* force sweep: branch-free fluid pair term, buffer addressing for list and gather */
 
 /* ms accumulated by sph_step since the last sph_reset_timings (HIP events on
  * the context's stream).  sort = K1+K2+K3 (initialize_particle_system),

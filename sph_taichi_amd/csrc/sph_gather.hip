@@ -325,6 +325,44 @@ __device__ __forceinline__ void pair_physics(const DevView& d, Target& t, float 
     }
 }
 
+// GM_FORCE_FUSED_U pair term, branch-free for a fluid neighbour (SPH_VAR_FORCE_BF): the formulas of pair_physics above
+// with (1 - q) clamped at 0, so W, grad W and with them every contribution vanish from r = h on exactly as if the pair
+// had been rejected (particle_system.py:385), and the self pair (r = 0) multiplies finite coefficients by r = 0.  Only a
+// solid neighbour still needs the accept test (its reaction is scattered with atomics).
+__device__ __forceinline__ void pair_force_u_bf(const DevView& d, Target& t, float rx, float ry, float rz, float r2,
+                                                const float4 A, const float4 B, int gj, bool not_self) {
+    const float rinv = __builtin_amdgcn_rsqf(r2 + 1e-30f);
+    const float rn = r2 * rinv;
+    const float q = rn * d.inv_h;
+    const float f = fminf(fmaxf(1.0f - q, 0.0f), 1.0f);
+    const float cin = d.k_dw * q * (3.0f * q - 2.0f), cout = d.k_dw * (-f * f);  // sph_base.py:46-68
+    const float cg = q <= 0.5f ? cin : cout;
+    const float gc = rn > 1e-5f ? cg * (rinv * d.inv_h) : 0.0f;
+    if (A.w > 0.0f) {
+        const float win = d.k_w * ((6.0f * q - 6.0f) * q * q + 1.0f), wout = d.k_w * 2.0f * (f * f * f);  // sph_base.py:23-44
+        const float wq = q <= 0.5f ? win : wout;
+        const float w = (r2 > d.d2) ? wq : d.w_d;
+        const float c = t.st_c * w;                                               // WCSPH.py:93-102
+        const float v_xy = (t.vx - B.x) * rx + (t.vy - B.y) * ry + (t.vz - B.z) * rz;
+        const float cv = d.visc_d_nu * A.w * v_xy * sph_rcp(r2 + d.visc_eps) * gc;  // WCSPH.py:105-116
+        const float k = cv - c;
+        t.ax += k * rx; t.ay += k * ry; t.az += k * rz;
+        const float cp = -d.rho0 * d.m_V0 * (t.dpi + B.w) * gc;                    // WCSPH.py:51-57
+        t.px += cp * rx; t.py += cp * ry; t.pz += cp * rz;
+    } else if (rn < d.h && not_self) {
+        const float cp = -d.rho0 * (-A.w) * (t.dpi + t.dpj_solid) * gc;            // WCSPH.py:58-68
+        const float fx = cp * rx, fy = cp * ry, fz = cp * rz;
+        t.px += fx; t.py += fy; t.pz += fz;
+        if (B.w != 0.0f) {
+            const float sc = d.rho0 * sph_rcp(d.aux[gj].y);  // density[p_j] of the body particle
+            float* a = reinterpret_cast<float*>(&d.acc[gj]);
+            unsafeAtomicAdd(a + 0, -fx * sc);
+            unsafeAtomicAdd(a + 1, -fy * sc);
+            unsafeAtomicAdd(a + 2, -fz * sc);
+        }
+    }
+}
+
 // write-back of one particle (target or not) for the given mode
 template <int MODE>
 __device__ __forceinline__ void target_finish(const DevView& d, Target& t, int i, bool gathered) {
@@ -628,13 +666,27 @@ __global__ __launch_bounds__(TPB) void k_brick_list(DevView d, int nbx, int nby,
     if (light) list[list_cap - 1 - (basel + __popcll(ml & below))] = b;
 }
 
-template <int MODE, class CFG>
+// a uniform value held in a VGPR: on gfx950 a VALU instruction with an SGPR source issues at half rate
+// (profiles/r02b_ubench_valu_table2.txt: v_fma_f32 with one SGPR operand 4.4 cycles, all-VGPR 2.6)
+__device__ __forceinline__ float sph_in_vgpr(float x) { float r; asm("v_mov_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ __forceinline__ unsigned sph_in_vgpr(unsigned x) { unsigned r; asm("v_mov_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+// raw buffer descriptor (gfx9 dword 3): byte offsets in a VGPR, hardware range check against `bytes`
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sph_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+template <int MODE, class CFG, int VAR = 0>
 __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nbz, const int* __restrict__ brick_list,
                                                       const int* __restrict__ brick_count,
                                                       unsigned short* __restrict__ glist,
                                                       unsigned char* __restrict__ gcnt, int cap, int list_cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool HAS_W = !mode_reads_list<MODE>();
+    constexpr bool V_PAD = (VAR & SPH_VAR_PAD) != 0;
+    constexpr bool V_2P = (VAR & SPH_VAR_2PHASE) != 0 && mode_inline_physics<MODE>();
+    constexpr bool V_MICRO = (VAR & SPH_VAR_MICRO) != 0;
+    constexpr bool V_BF = (VAR & SPH_VAR_FORCE_BF) != 0 && MODE == GM_FORCE_FUSED_U;
+    constexpr bool INLINE_PHYS = mode_inline_physics<MODE>() && !V_2P;  // pair terms inside the emission loop
     float4* sQ = reinterpret_cast<float4*>(smem + CFG::OFF_Q);
     float* sW = reinterpret_cast<float*>(smem + CFG::off_w(HAS_W));  // only when HAS_W
     // Shell origin.  Candidates are staged in shell-local coordinates as (-2x', -2y', -2z', |x'|^2) so the
@@ -799,6 +851,14 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
             // superset filter (exact r < h test in phase 2): r2 - |x_i'|^2 < h^2 (1 + 2e-4) - |x_i'|^2
             const float thr = d.h * d.h * 1.0002f - (txl_ * txl_ + tyl_ * tyl_ + tzl_ * tzl_);
             unsigned short* const gl = glist + gi;  // row k of this target's list: gl[k * cap]
+            // V_MICRO: the list rows through a raw buffer whose size is LISTCAP rows -- a store into row >= LISTCAP is
+            // dropped by the hardware range check (no compare, no branch), the byte offset is one 32-bit VGPR
+            const __amdgpu_buffer_rsrc_t lrs = sph_rsrc(glist, (unsigned)CFG::LISTCAP * (unsigned)cap * 2u);
+            unsigned voff = (unsigned)gi * 2u;
+            const unsigned vcap2 = V_MICRO ? sph_in_vgpr((unsigned)cap * 2u) : 0u;
+            const float v_inv_h = V_MICRO ? sph_in_vgpr(d.inv_h) : d.inv_h, v_kw = V_MICRO ? sph_in_vgpr(d.k_w) : d.k_w;
+            const float v_kw2 = V_MICRO ? sph_in_vgpr(d.k_w * 2.0f) : d.k_w * 2.0f;
+            (void)gl; (void)lrs; (void)voff; (void)vcap2; (void)v_inv_h; (void)v_kw; (void)v_kw2;
             // phase 1: filter the 9 column runs into the private index list (4 LDS slots in flight)
             for (int dx = -1; dx <= 1; ++dx) {
                 const int nx = ix + dx;
@@ -820,11 +880,17 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
                     for (int base = lo; base < hi; base += 32) {
                         const int n = min(32, hi - base);
                         unsigned mask = 0;
-                        int k = n;
-                        while (k & 7) {  // the ragged end first
-                            --k;
-                            const float4 q0 = sQ[base + k];
-                            SPH_ACC(q0);
+                        // V_PAD: whole groups of 8 only.  Up to 7 records past the run's end are tested too (they are
+                        // the next run's, or the first bytes of the m_V array behind the last record: always inside
+                        // this workgroup's LDS) and their bits are cleared afterwards -- 7 wasted tests at 5 VALU each
+                        // instead of up to 7 one-candidate trips that each wait for their own ds_read.
+                        int k = V_PAD ? ((n + 7) & ~7) : n;
+                        if (!V_PAD) {
+                            while (k & 7) {  // the ragged end first
+                                --k;
+                                const float4 q0 = sQ[base + k];
+                                SPH_ACC(q0);
+                            }
                         }
                         while (k > 0) {
                             k -= 8;
@@ -834,13 +900,36 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
                             SPH_ACC(q7); SPH_ACC(q6); SPH_ACC(q5); SPH_ACC(q4);
                             SPH_ACC(q3); SPH_ACC(q2); SPH_ACC(q1); SPH_ACC(q0);
                         }
+                        if (V_PAD) mask &= 0xffffffffu >> (32 - n);
                         const unsigned tagbase = tag | (unsigned)base;
+                        if (V_MICRO) {
+                            const unsigned base16 = (unsigned)base << 4;
+                            cnt += __popc(mask);
+                            while (mask) {
+                                const unsigned bit = (unsigned)__ffs((int)mask) - 1u;
+                                mask &= mask - 1u;
+                                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(tagbase + bit), lrs, (int)voff, 0, 0);
+                                voff += vcap2;
+                                if (INLINE_PHYS) {  // the same pair term as below, addresses and constants arranged for the issue rates
+                                    const unsigned aq = base16 + (bit << 4);
+                                    const float4 q4 = *reinterpret_cast<const float4*>(smem + CFG::OFF_Q + aq);
+                                    const float mVj = *reinterpret_cast<const float*>(smem + CFG::off_w(true) + (aq >> 2));
+                                    const float rx = fmaf(0.5f, q4.x, txl_), ry = fmaf(0.5f, q4.y, tyl_), rz = fmaf(0.5f, q4.z, tzl_);
+                                    const float r2 = rx * rx + ry * ry + rz * rz;
+                                    const float qn = r2 * __builtin_amdgcn_rsqf(r2 + 1e-30f) * v_inv_h;  // r2 = 0 (self): 0 * 1e15 = 0
+                                    const float tq = fminf(fmaxf(1.0f - qn, 0.0f), 1.0f);                // one v_fma ... clamp
+                                    const float inner = v_kw * ((6.0f * qn - 6.0f) * qn * qn + 1.0f);
+                                    const float outer = v_kw2 * (tq * tq * tq);
+                                    t.s0 += mVj * (qn <= 0.5f ? inner : outer);
+                                }
+                            }
+                        } else
                         while (mask) {  // rows coalesce across the wave's lanes (consecutive gi)
                             const unsigned bit = (unsigned)__ffs((int)mask) - 1u;
                             mask &= mask - 1u;
                             if (cnt < CFG::LISTCAP) gl[(size_t)cnt * cap] = (unsigned short)(tagbase + bit);
                             ++cnt;
-                            if (mode_inline_physics<MODE>()) {
+                            if (INLINE_PHYS) {
                                 // The density pair term is cheap: do it here instead of re-reading the list, and
                                 // branch-free: (1-q) is clamped at 0, so W vanishes for r >= h exactly as if the
                                 // pair had been rejected (particle_system.py:385); the self pair (r = 0) supplies
@@ -868,7 +957,7 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
             const bool list_ovf = cnt > CFG::LISTCAP && !(d.ablate & 8);
             // (flat cell 0's own range is never visited -- the reference's max(0, idx-1) quirk -- so a target that
             // lives there does not meet itself in the list and keeps the explicit self term)
-            if (mode_inline_physics<MODE>()) t.self_in_sum = key_i != 0;
+            if (INLINE_PHYS) t.self_in_sum = key_i != 0;
             else if (list_ovf) walk = true;
             if (mode_writes_list<MODE>()) gcnt[gi] = (unsigned char)(walk ? SPH_CNT_WALK : list_ovf ? SPH_CNT_LIST_OVF : cnt);
             __threadfence_block();  // this lane re-reads its own entries below
@@ -878,6 +967,41 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
             if (cnt >= SPH_CNT_LIST_OVF) { walk = true; cnt = 0; }
         }
         if (mode_writes_list<MODE>() && g && overflow) gcnt[gi] = (unsigned char)SPH_CNT_WALK;
+        if (V_2P && g && !walk && !overflow && !(d.ablate & 1)) {
+            // V_2P, phase 2 of the density sweep: ONE loop over the lane's own list.  Its trip count is the wave's
+            // longest list (33 on a rest lattice, ~46 in a settled flow) where the inline form pays the sum over the
+            // nine runs of the wave's per-run maxima (70 / ~110, tools/emission_model.py).  Row k of all 64 lanes is
+            // one 128-byte line just written by this wave (L2-resident); four rows are in flight ahead of the physics.
+            const float txl_ = t.x - Ox, tyl_ = t.y - Oy, tzl_ = t.z - Oz;
+            const float v_inv_h = V_MICRO ? sph_in_vgpr(d.inv_h) : d.inv_h, v_kw = V_MICRO ? sph_in_vgpr(d.k_w) : d.k_w;
+            const float v_kw2 = V_MICRO ? sph_in_vgpr(d.k_w * 2.0f) : d.k_w * 2.0f;
+            const __amdgpu_buffer_rsrc_t lrs2 = sph_rsrc(glist, (unsigned)SPH_GLIST_ROWS * (unsigned)cap * 2u);
+            const unsigned cap2 = (unsigned)cap * 2u;
+            const int vg = gi * 2;
+            auto lde = [&](int row) -> unsigned {  // (row is wave-uniform: the row offset is a scalar; glc: past this CU's L1)
+                return (unsigned)__builtin_amdgcn_raw_buffer_load_b16(lrs2, vg, (int)((unsigned)min(row, CFG::LISTCAP - 1) * cap2), 1);
+            };
+            auto dens_one = [&](unsigned e, bool live) {
+                const unsigned aq = (e << 4) & 0x7ff0u;  // LDS byte offset of the record (slot = low 11 bits of the entry)
+                const float4 q4 = *reinterpret_cast<const float4*>(smem + CFG::OFF_Q + aq);
+                const float mVj = *reinterpret_cast<const float*>(smem + CFG::off_w(true) + (aq >> 2));
+                const float rx = fmaf(0.5f, q4.x, txl_), ry = fmaf(0.5f, q4.y, tyl_), rz = fmaf(0.5f, q4.z, tzl_);
+                const float r2 = rx * rx + ry * ry + rz * rz;
+                const float qn = r2 * __builtin_amdgcn_rsqf(r2 + 1e-30f) * v_inv_h;
+                const float tq = fminf(fmaxf(1.0f - qn, 0.0f), 1.0f);
+                const float inner = v_kw * ((6.0f * qn - 6.0f) * qn * qn + 1.0f);
+                const float outer = v_kw2 * (tq * tq * tq);
+                const float w = mVj * (qn <= 0.5f ? inner : outer);
+                t.s0 += live ? w : 0.0f;
+            };
+            unsigned e0 = lde(0), e1 = lde(1), e2 = lde(2), e3 = lde(3);
+            for (int k = 0; k < cnt; k += 4) {
+                const unsigned c0 = e0, c1 = e1, c2 = e2, c3 = e3;
+                e0 = lde(k + 4); e1 = lde(k + 5); e2 = lde(k + 6); e3 = lde(k + 7);
+                dens_one(c0, true); dens_one(c1, k + 1 < cnt); dens_one(c2, k + 2 < cnt); dens_one(c3, k + 3 < cnt);
+            }
+            t.self_in_sum = key_i != 0;  // the self pair is a list entry (W(0) term of WCSPH.py:39), except in flat cell 0
+        }
         if (g && !walk && !(d.ablate & 1) && !mode_inline_physics<MODE>()) {
             // phase 2: pair physics over the list.  Register sets rotate: while pair k is computed from one, the
             // records of the next entries are in flight into the others.  Every fetch is UNCONDITIONAL (past the end it re-reads
@@ -886,11 +1010,20 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
             const float txl = t.x - Ox, tyl = t.y - Oy, tzl = t.z - Oz;
             (void)txl; (void)tyl; (void)tzl;
             struct Slot { float4 A, B, C; int g, j; };
+            // V_BF: list rows and the gat gather through raw buffers (32-bit byte offsets instead of 64-bit pointer arithmetic)
+            const __amdgpu_buffer_rsrc_t grs = sph_rsrc(d.gat, (unsigned)d.N * 16u);
+            const __amdgpu_buffer_rsrc_t lrs3 = sph_rsrc(glist, (unsigned)SPH_GLIST_ROWS * (unsigned)cap * 2u);
+            (void)grs; (void)lrs3;
             auto fetch = [&](Slot& s_, unsigned e) {
                 s_.j = e & 2047;
                 s_.A = sQ[s_.j];  // list-reading sweeps: (x, y, z, m_V)
                 if (HAS_W) s_.A.w = sW[s_.j];
                 s_.g = sColG[e >> 11] + s_.j;
+                if (V_BF) {
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+                    const v4f b = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(grs, s_.g << 4, 0, 0));
+                    s_.B = make_float4(b.x, b.y, b.z, b.w);
+                } else
                 s_.B = mode_needs_B<MODE>() ? (MODE == GM_FORCE_FUSED_U ? d.gat : d.vf)[s_.g] : make_float4(0.f, 0.f, 0.f, 0.f);
                 s_.C = mode_needs_C<MODE>() ? load_C_global<MODE>(d, s_.g) : make_float4(0.f, 0.f, 0.f, 0.f);
                 if (mode_is_df_iter_u<MODE>()) s_.C.x = d.kbuf[s_.g];  // the one 4-byte gather of these sweeps
@@ -901,6 +1034,7 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
                 const float ry = HAS_W ? fmaf(0.5f, s_.A.y, tyl) : t.y - s_.A.y;
                 const float rz = HAS_W ? fmaf(0.5f, s_.A.z, tzl) : t.z - s_.A.z;
                 const float r2 = rx * rx + ry * ry + rz * rz;
+                if (V_BF) { pair_force_u_bf(d, t, rx, ry, rz, r2, s_.A, s_.B, s_.g, s_.j != li); return; }
                 const float rinv = sph_rsq(r2);
                 const float rn = r2 * rinv;
                 if (sph_within<MODE>(d, r2, rn) && s_.j != li)  // particle_system.py:385
@@ -909,19 +1043,25 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
             if (cnt > 0) {
                 const unsigned short* gl = glist + gi;  // entry k of this target: gl[k * cap]
                 const int last = cnt - 1;
+                const unsigned vlast = ((unsigned)last * (unsigned)cap + (unsigned)gi) * 2u;
+                // entry `row` of this lane, clamped to its last one (row is wave-uniform: row * cap is scalar arithmetic)
+                auto lde = [&](int row) -> unsigned {
+                    if (V_BF) return (unsigned)__builtin_amdgcn_raw_buffer_load_b16(lrs3, (int)min(((unsigned)row * (unsigned)cap + (unsigned)gi) * 2u, vlast), 0, 0);
+                    return gl[(size_t)min(row, last) * cap];
+                };
                 Slot s0, s1, s2;  // three sets: the records of entries k+1 and k+2 are in flight while pair k is computed
-                unsigned ea = gl[0], eb = gl[(size_t)min(1, last) * cap], ec = gl[(size_t)min(2, last) * cap];
+                unsigned ea = lde(0), eb = lde(1), ec = lde(2);
                 fetch(s0, ea);
                 fetch(s1, eb);
                 for (int k = 0; k < cnt; k += 3) {
                     fetch(s2, ec);
-                    ea = gl[(size_t)min(k + 3, last) * cap];
+                    ea = lde(k + 3);
                     pair(s0);
                     fetch(s0, ea);
-                    eb = gl[(size_t)min(k + 4, last) * cap];
+                    eb = lde(k + 4);
                     if (k + 1 < cnt) pair(s1);
                     fetch(s1, eb);
-                    ec = gl[(size_t)min(k + 5, last) * cap];
+                    ec = lde(k + 5);
                     if (k + 2 < cnt) pair(s2);
                 }
             }
@@ -963,7 +1103,7 @@ static int launch_simple(SphContext* c, const int* list, int n) {
     return 0;
 }
 
-template <int MODE, class CFG>
+template <int MODE, class CFG, int VAR = 0>
 static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, int hi2 = 0) {
     DevView d = sph_view(c);
     if (MODE == GM_DENSITY_EOS) { d.tgt_lo = c->tgt_layers[0]; d.tgt_hi = c->tgt_layers[1]; d.write_sg = c->uniform_state == 1; }
@@ -982,7 +1122,7 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
     static bool attr_set[64] = {};  // per device: the attribute belongs to the function ON a device
     const int dev = c->device >= 0 && c->device < 64 ? c->device : 0;
     if (!attr_set[dev]) {
-        SPH_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gather_brick<MODE, CFG>),
+        SPH_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gather_brick<MODE, CFG, VAR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         attr_set[dev] = true;
     }
@@ -1003,7 +1143,7 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
             c->bricks_valid = true;
         }
     }
-    hipLaunchKernelGGL((k_gather_brick<MODE, CFG>), dim3(grid), dim3(TPB), bytes, st, d, nby, nbz, blist, bcount, c->glist,
+    hipLaunchKernelGGL((k_gather_brick<MODE, CFG, VAR>), dim3(grid), dim3(TPB), bytes, st, d, nby, nbz, blist, bcount, c->glist,
                        c->gcnt, c->cap, c->brick_cap);
     SPH_LAUNCH_CHECK(c);
     return 0;
@@ -1015,8 +1155,28 @@ static int launch_brick(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, in
         case 1: return launch_brick_cfg<MODE, Cfg1>(c, lo, hi, lo2, hi2);
         case 2: return launch_brick_cfg<MODE, Cfg2>(c, lo, hi, lo2, hi2);
         case 3: return launch_brick_cfg<MODE, Cfg3>(c, lo, hi, lo2, hi2);
-        default: return launch_brick_cfg<MODE, Cfg0>(c, lo, hi, lo2, hi2);
+        default: break;
     }
+    // SPH_OPT_KERNEL_VARIANT: A/B instances of the two sweeps of the fused WCSPH step (default brick shape only).
+    // The buffer-addressed variants hold byte offsets in 32 bits: 64 list rows of 2 * cap bytes must fit.
+    int var = c->opt_variant;
+    if ((unsigned long long)c->cap * 2ull * SPH_GLIST_ROWS >= (1ull << 32)) var &= SPH_VAR_PAD;
+    if constexpr (MODE == GM_DENSITY_EOS) {
+        switch (var & 7) {
+            case 1: return launch_brick_cfg<MODE, Cfg0, 1>(c, lo, hi, lo2, hi2);
+            case 2: return launch_brick_cfg<MODE, Cfg0, 2>(c, lo, hi, lo2, hi2);
+            case 3: return launch_brick_cfg<MODE, Cfg0, 3>(c, lo, hi, lo2, hi2);
+            case 4: return launch_brick_cfg<MODE, Cfg0, 4>(c, lo, hi, lo2, hi2);
+            case 5: return launch_brick_cfg<MODE, Cfg0, 5>(c, lo, hi, lo2, hi2);
+            case 6: return launch_brick_cfg<MODE, Cfg0, 6>(c, lo, hi, lo2, hi2);
+            case 7: return launch_brick_cfg<MODE, Cfg0, 7>(c, lo, hi, lo2, hi2);
+            default: break;
+        }
+    }
+    if constexpr (MODE == GM_FORCE_FUSED_U) {
+        if (var & SPH_VAR_FORCE_BF) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_FORCE_BF>(c, lo, hi, lo2, hi2);
+    }
+    return launch_brick_cfg<MODE, Cfg0>(c, lo, hi, lo2, hi2);
 }
 
 // force sweep over the targets of x layers [lo, hi) only (slab mode: boundary layers first, interior later)

@@ -27,6 +27,7 @@
 #define SPH_MAX_TIMED_STEPS 128
 #define SPH_GLIST_ROWS 64
 #define SPH_DF_ERR_BLOCKS 512
+#define SPH_VAR_DEFAULT 0  // SPH_OPT_KERNEL_VARIANT when the caller does not choose (set from the measured A/B table)
 
 struct DevView {
     int N, G;
@@ -134,6 +135,7 @@ struct SphContext {
     // options
     int opt_gather_impl, opt_timing, opt_fused, opt_brick_shape, opt_no_dynamic, opt_ablate, opt_drop_outside;
     int opt_sort_by_pid;
+    int opt_variant;     // SPH_OPT_KERNEL_VARIANT (bit mask of SPH_VAR_*)
     int fuse_advect;     // set around the force launch of sph_step when the advect can ride in its finish
     int opt_uniform;     // SPH_OPT_UNIFORM_FLUID: -1 auto, 0 off, 1 check once
     int uniform_state;   // -1 unknown, 0 the precondition fails, 1 holds (m_uniform valid)

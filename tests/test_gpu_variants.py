@@ -1,0 +1,78 @@
+"""SPH_OPT_KERNEL_VARIANT: every A/B instance of the fused step's two brick sweeps (padded filter groups, two-phase
+density, issue-rate-arranged emission loop, branch-free force pair term) computes the reference's sums -- each against
+the CPU oracle on the coupled scene, on crowded cells (list overflow -> exact walk), and against variant 0."""
+import numpy as np
+import pytest
+
+import scenes
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = list(range(16))
+
+
+def _system(sd, arrays, variant):
+    from sph_taichi_amd import _lib
+    ps, solver = scenes.make_ps(sd, arrays)
+    ps.set_option(_lib.OPT_KERNEL_VARIANT, variant)
+    assert ps.get_option(_lib.OPT_KERNEL_VARIANT) == variant
+    return ps, solver
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_variant_follows_the_oracle(variant):
+    sd = scenes.fluid_with_rigid_blocks()
+    cfg, sc = scenes.build(sd)
+    scenes.jitter(sc, 0.1, seed=4)
+    o = scenes.make_oracle(cfg, sc)
+    ps, solver = _system(sd, sc.arrays, variant)
+    o.initialize(); solver.initialize()
+    o.step(1); solver.step(1)
+    for name, tol in (("density", 2e-5), ("pressure", 2e-4), ("acceleration", 5e-4)):
+        ref, got = o.by_pid(name), scenes.ps_by_pid(ps, name)
+        err = float(np.abs(got.astype(np.float64) - ref).max()) / max(float(np.abs(ref).max()), 1e-30)
+        assert err <= tol, f"variant {variant}: {name} after one step: {err:.3e} > {tol:.1e}"
+    o.step(19); solver.step(19)
+    err = scenes.rel_l2(scenes.ps_by_pid(ps, "x"), o.by_pid("x"))
+    assert err <= 1e-4, f"variant {variant}: rel-L2(x) after 20 steps = {err:.3e}"
+    ps.close()
+
+
+@pytest.mark.parametrize("variant", [1, 2, 4, 7, 15])
+def test_variant_on_crowded_cells(variant):
+    """12^3 particles in a (1.5 h)^3 box: > 63 neighbours each, so every list overflows (the two-phase density must
+    fall back to the exact walk; the range-checked list stores must drop rows >= LISTCAP and nothing else)."""
+    sd = scenes.fluid_only(counts=(12, 12, 12), start=(0.3, 0.3, 0.3))
+    cfg, sc = scenes.build(sd)
+    rng = np.random.default_rng(0)
+    sc.arrays["x"] = (0.3 + rng.uniform(0, 0.06, size=sc.arrays["x"].shape)).astype(np.float32)
+    sc.arrays["x_0"] = sc.arrays["x"].copy()
+    o = scenes.make_oracle(cfg, sc)
+    ps, solver = _system(sd, sc.arrays, variant)
+    o.initialize(); solver.initialize()
+    o.step(1); solver.step(1)
+    for name, tol in (("density", 5e-5), ("acceleration", 5e-3)):
+        ref, got = o.by_pid(name), scenes.ps_by_pid(ps, name)
+        err = float(np.abs(got.astype(np.float64) - ref).max()) / max(float(np.abs(ref).max()), 1e-30)
+        assert err <= tol, f"variant {variant}: crowded {name}: {err:.3e}"
+    ps.close()
+
+
+def test_variants_agree_with_each_other_on_a_ragged_lattice():
+    """A lattice whose nodes sit on cell faces (run lengths 1..27 per cell, the benchmark's initial state): the padded
+    filter reads past every run's end; all variants must produce variant 0's densities and accelerations."""
+    sd = scenes.fluid_only(counts=(18, 14, 16), start=(0.04, 0.04, 0.04), velocity=(0.3, -0.2, 0.1))
+    cfg, sc = scenes.build(sd)
+    base = None
+    for variant in VARIANTS:
+        ps, solver = _system(sd, sc.arrays, variant)
+        solver.initialize()
+        solver.step(3)
+        got = {n: scenes.ps_by_pid(ps, n).astype(np.float64) for n in ("density", "acceleration", "x")}
+        ps.close()
+        if base is None:
+            base = got
+            continue
+        for n, tol in (("density", 2e-6), ("acceleration", 2e-5), ("x", 1e-7)):
+            err = float(np.abs(got[n] - base[n]).max()) / max(float(np.abs(base[n]).max()), 1e-30)
+            assert err <= tol, f"variant {variant} vs 0: {n}: {err:.3e}"

@@ -1,0 +1,128 @@
+"""Lock-step trip counts of the density sweep's emission loop under different orderings (CPU model, no GPU).
+
+A wave = 64 consecutive targets of a brick; every target has 9 column runs.  The emission loop runs, per phase, as
+many trips as the wave's busiest lane has hits in the run it handles in that phase.  This script settles a small
+box with the CPU oracle (test infrastructure), then counts trips for
+  natural   : every lane walks its runs in (dx, dy) order                                (r01 kernel)
+  mirrored  : every lane walks its runs near side first (dx order reversed in the upper half of its cell, same for dy)
+  sorted    : every lane walks its runs by descending own hit count (bound for any per-lane permutation)
+  merged    : one loop over the lane's total (bound for any scheme)
+Usage: python tools/emission_model.py [--n 28] [--steps 1500] [--fill 1.0]
+"""
+from __future__ import annotations
+
+import argparse
+import copy
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def settle(n, steps, threads):
+    import scenes
+    d = 0.02
+    start = (0.04, 0.04, 0.04)
+    sd = scenes.fluid_only(counts=(n, n, n), start=start, velocity=(0.6, -1.0, 0.3),
+                           domain_end=(start[0] + n * d + 0.12, start[1] + n * d * 1.6, start[2] + n * d + 0.12))
+    cfg, sc = scenes.build(copy.deepcopy(sd))
+    o = scenes.make_oracle(cfg, sc, omp_threads=threads)
+    o.initialize()
+    x0 = o.by_pid("x").copy()
+    if steps:
+        o.step(steps)
+    return x0, o.by_pid("x").copy(), sc.geom
+
+
+def analyse(x, h, label, BX=4, BY=2, BZ=4, margin=1.0002):
+    cell = np.floor(x / h).astype(np.int64)
+    lo = cell.min(0)
+    cell -= lo
+    nx, ny, nz = cell.max(0) + 1
+    key = (cell[:, 0] * ny + cell[:, 1]) * nz + cell[:, 2]
+    order = np.argsort(key, kind="stable")
+    x = x[order]; cell = cell[order]; key = key[order]
+    G = nx * ny * nz
+    cnt = np.bincount(key, minlength=G)
+    end = np.cumsum(cnt)
+    beg = end - cnt
+    frac = x / h - np.floor(x / h)
+    h2 = h * h * margin
+    N = len(x)
+    # per target: hits per run [9] in natural (dx, dy) order, run lengths [9]
+    hits = np.zeros((N, 9), np.int32)
+    rlen = np.zeros((N, 9), np.int32)
+    for r, (dx, dy) in enumerate((a, b) for a in (-1, 0, 1) for b in (-1, 0, 1)):
+        cx = cell[:, 0] + dx; cy = cell[:, 1] + dy
+        ok = (cx >= 0) & (cx < nx) & (cy >= 0) & (cy < ny)
+        zlo = np.maximum(cell[:, 2] - 1, 0); zhi = np.minimum(cell[:, 2] + 1, nz - 1)
+        klo = (np.where(ok, cx, 0) * ny + np.where(ok, cy, 0)) * nz + zlo
+        khi = (np.where(ok, cx, 0) * ny + np.where(ok, cy, 0)) * nz + zhi
+        b = beg[klo]; e = end[khi]
+        L = np.where(ok, e - b, 0)
+        rlen[:, r] = L
+        for k in range(int(L.max())):
+            m = k < L
+            j = np.where(m, b + k, 0)
+            dd = x - x[j]
+            hits[:, r] += (m & ((dd * dd).sum(1) < h2)).astype(np.int32)
+    # interior targets only (full neighbourhoods), grouped into bricks then waves of 64 consecutive targets
+    sx = frac[:, 0] >= 0.5; sy = frac[:, 1] >= 0.5
+    perm_nat = np.arange(9)
+    res = dict(natural=0, mirrored=0, sorted=0, merged=0, ideal=0.0, filt_nat=0, waves=0, lanes=0)
+    bxs = range(1, (nx - 2) // BX); bys = range(1, (ny - 2) // BY); bzs = range(1, (nz - 2) // BZ)
+    idx_of = {}
+    for bx in bxs:
+        for by in bys:
+            for bz in bzs:
+                t = []
+                for ix in range(bx * BX, bx * BX + BX):
+                    for iy in range(by * BY, by * BY + BY):
+                        k0 = (ix * ny + iy) * nz + bz * BZ
+                        t.extend(range(beg[k0], end[k0 + BZ - 1]))
+                t = np.array(t, np.int64)
+                if len(t) < 64:
+                    continue
+                for w in range(0, len(t) - 63, 64):
+                    ids = t[w:w + 64]
+                    H = hits[ids]
+                    res["natural"] += int(H.max(0).sum())
+                    # mirrored: phase (px, py) -> run (sx ? 2-px : px, sy ? 2-py : py)
+                    M = np.empty_like(H)
+                    for p in range(9):
+                        px, py = divmod(p, 3)
+                        rx = np.where(sx[ids], 2 - px, px); ry = np.where(sy[ids], 2 - py, py)
+                        M[:, p] = H[np.arange(64), rx * 3 + ry]
+                    res["mirrored"] += int(M.max(0).sum())
+                    res["sorted"] += int((-np.sort(-H, axis=1)).max(0).sum())
+                    res["merged"] += int(H.sum(1).max())
+                    res["ideal"] += float(H.sum(1).mean())
+                    res["filt_nat"] += int((((rlen[ids] + 7) // 8) * 8).max(0).sum())
+                    res["waves"] += 1
+    w = max(res["waves"], 1)
+    print(f"{label}: {N} particles, mean cell occupancy {cnt[cnt > 0].mean():.2f} (max {cnt.max()}), {w} interior waves")
+    print(f"   mean hits per lane {res['ideal'] / w:.1f};  emission trips per wave: natural {res['natural'] / w:.1f}, "
+          f"mirrored {res['mirrored'] / w:.1f}, sorted {res['sorted'] / w:.1f}, merged {res['merged'] / w:.1f};  "
+          f"filter candidates per wave (lock-step, 8 per trip) {res['filt_nat'] / w:.0f}")
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=28)
+    ap.add_argument("--steps", type=int, default=1500)
+    ap.add_argument("--threads", type=int, default=os.cpu_count())
+    a = ap.parse_args()
+    x0, x1, geom = settle(a.n, a.steps, a.threads)
+    h = geom.support_radius if hasattr(geom, "support_radius") else 4 * geom.particle_radius
+    analyse(x0.astype(np.float64), h, "rest lattice")
+    if a.steps:
+        analyse(x1.astype(np.float64), h, f"after {a.steps} steps")
+
+
+if __name__ == "__main__":
+    main()

@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--gather-impl", type=int, default=1)
     ap.add_argument("--brick-shape", type=int, default=0)
     ap.add_argument("--fused", type=int, default=1)
+    ap.add_argument("--variant", type=int, default=-1, help="SPH_OPT_KERNEL_VARIANT mask (-1 = the library's default)")
     ap.add_argument("--cpu-steps", type=int, default=10, help="CPU-oracle sample size (0 = skip the baseline leg)")
     ap.add_argument("--sweep", action="store_true", help="also time every gather variant (stderr table)")
     ap.add_argument("--ablate", action="store_true", help="profiling: time the sweeps with sections skipped (stderr)")
@@ -189,6 +190,7 @@ def main():
         return dt, tm
 
     solver.initialize()
+    ps.set_option(_lib.OPT_KERNEL_VARIANT, args.variant)
     if args.settle > 0:
         solver.step(args.settle)
         ps.sync()
@@ -208,7 +210,8 @@ def main():
         # same particle state for every variant: sweeps only (no advect), positions frozen by dt = 0
         solver.step(args.warmup)
         solver.dt[None] = 0.0
-        for mask, what in [(0, "full"), (1, "no phase 2"), (2, "no list write-out"), (3, "no phase 2, no write-out"),
+        for mask, what in [(0, "full"), (1, "no phase 2"), (2, "no list write-out (force sweep reads stale lists)"),
+                           (16, "filter only, no hit emitted"), (32, "no pair term in the emission loop"), (34, "emission: bit loop only"),
                            (4, "no phase 1"), (7, "staging + target setup only")]:
             ps.set_option(_lib.OPT_DEBUG_ABLATE, mask)
             dt, tm = run(args.gather_impl, args.brick_shape, 1, 20, 2)
@@ -282,7 +285,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.workload, "particles": N, "cells": G, "dt": CFG["timeStepSize"],
                    "gather_impl": args.gather_impl, "brick_shape": args.brick_shape, "fused": args.fused,
-                   "parallelism": "1 GPU"},
+                   "kernel_variant": ps.get_option(_lib.OPT_KERNEL_VARIANT), "parallelism": "1 GPU"},
         "breakdown_ms": {"sort": round(tm.sort_ms / k, 4), "neighbour": round(neigh_ms, 4),
                          "force": round(force_ms, 4), "integrate": round(tm.integrate_ms / k, 4),
                          "sum_of_phases": round(tm.total_ms / k, 4)},

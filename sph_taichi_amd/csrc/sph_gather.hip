@@ -380,7 +380,8 @@ __device__ __forceinline__ void target_finish(const DevView& d, Target& t, int i
         float4 aux = d.aux[i];
         float4 e;
         if (gathered) {
-            const float rho_raw = (t.self_in_sum ? t.s0 : t.mV * d.w_zero + t.s0) * d.rho0;  // WCSPH.py:39-43
+            float rho_raw = (t.self_in_sum ? t.s0 : t.mV * d.w_zero + t.s0) * d.rho0;  // WCSPH.py:39-43
+            if (d.ablate & (1 | 16 | 32)) rho_raw = d.rho0;  // profiling runs that skip pair terms: keep the state finite
             const float rho = fmaxf(rho_raw, d.rho0);                 // WCSPH.py:75
             // WCSPH.py:76 ti.pow(rho / rho0, exponent): integer exponents by multiplication (sph_tait_pow); the ratio is
             // the IEEE quotient (once per particle; its error is amplified by stiffness * exponent), the later
@@ -901,6 +902,7 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
                             SPH_ACC(q3); SPH_ACC(q2); SPH_ACC(q1); SPH_ACC(q0);
                         }
                         if (V_PAD) mask &= 0xffffffffu >> (32 - n);
+                        if (d.ablate & 16) mask &= (d.ablate >> 8);  // profiling: filter only (mask kept live, no hit emitted)
                         const unsigned tagbase = tag | (unsigned)base;
                         if (V_MICRO) {
                             const unsigned base16 = (unsigned)base << 4;
@@ -908,9 +910,9 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
                             while (mask) {
                                 const unsigned bit = (unsigned)__ffs((int)mask) - 1u;
                                 mask &= mask - 1u;
-                                __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(tagbase + bit), lrs, (int)voff, 0, 0);
+                                if (!(d.ablate & 2)) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(tagbase + bit), lrs, (int)voff, 0, 0);
                                 voff += vcap2;
-                                if (INLINE_PHYS) {  // the same pair term as below, addresses and constants arranged for the issue rates
+                                if (INLINE_PHYS && !(d.ablate & 32)) {  // the same pair term as below, addresses and constants arranged for the issue rates
                                     const unsigned aq = base16 + (bit << 4);
                                     const float4 q4 = *reinterpret_cast<const float4*>(smem + CFG::OFF_Q + aq);
                                     const float mVj = *reinterpret_cast<const float*>(smem + CFG::off_w(true) + (aq >> 2));
@@ -927,9 +929,9 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
                         while (mask) {  // rows coalesce across the wave's lanes (consecutive gi)
                             const unsigned bit = (unsigned)__ffs((int)mask) - 1u;
                             mask &= mask - 1u;
-                            if (cnt < CFG::LISTCAP) gl[(size_t)cnt * cap] = (unsigned short)(tagbase + bit);
+                            if (cnt < CFG::LISTCAP && !(d.ablate & 2)) gl[(size_t)cnt * cap] = (unsigned short)(tagbase + bit);
                             ++cnt;
-                            if (INLINE_PHYS) {
+                            if (INLINE_PHYS && !(d.ablate & 32)) {
                                 // The density pair term is cheap: do it here instead of re-reading the list, and
                                 // branch-free: (1-q) is clamped at 0, so W vanishes for r >= h exactly as if the
                                 // pair had been rejected (particle_system.py:385); the self pair (r = 0) supplies

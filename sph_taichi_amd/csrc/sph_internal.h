@@ -27,7 +27,7 @@
 #define SPH_MAX_TIMED_STEPS 128
 #define SPH_GLIST_ROWS 64
 #define SPH_DF_ERR_BLOCKS 512
-#define SPH_VAR_DEFAULT 0  // SPH_OPT_KERNEL_VARIANT when the caller does not choose (set from the measured A/B table)
+#define SPH_VAR_DEFAULT (SPH_VAR_PAD | SPH_VAR_MICRO)  // SPH_OPT_KERNEL_VARIANT when the caller does not choose: the fastest row of profiles/r02c_variants.json
 
 struct DevView {
     int N, G;

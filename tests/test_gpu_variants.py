@@ -16,6 +16,9 @@ def _system(sd, arrays, variant):
     ps, solver = scenes.make_ps(sd, arrays)
     ps.set_option(_lib.OPT_KERNEL_VARIANT, variant)
     assert ps.get_option(_lib.OPT_KERNEL_VARIANT) == variant
+    ps.set_option(_lib.OPT_KERNEL_VARIANT, -1)            # -1 = the library's default mask
+    assert ps.get_option(_lib.OPT_KERNEL_VARIANT) == (_lib.VAR_PAD | _lib.VAR_MICRO)
+    ps.set_option(_lib.OPT_KERNEL_VARIANT, variant)
     return ps, solver
 
 

@@ -84,9 +84,11 @@ def _scene_dict(workload: str):
                              "scale": [1, 1, 1], "velocity": vel, "density": 1000.0, "color": [50, 100, 200]}]}
 
 
-def cpu_baseline(sd, sample_steps: int):
-    """Time the CPU oracle on a bounded sample of the same workload (rank 0, N=1 only)."""
-    from oracle.oracle import Oracle, max_threads
+def cpu_baseline(sd, sample_steps: int, repeats: int = 3):
+    """Time the CPU oracle on a bounded sample of the same workload (rank 0, N=1 only): the timing build of
+    oracle/sph_oracle.c (-O3 -march=native, compiled here on this host), OpenMP over every
+    core the process may use, median of `repeats` samples of `sample_steps` steps each."""
+    from oracle.oracle import Oracle, lib
     from sph_taichi_amd.config_builder import SimConfig
     from sph_taichi_amd import scene as scene_mod
     cfg = SimConfig(config=copy.deepcopy(sd))
@@ -96,21 +98,40 @@ def cpu_baseline(sd, sample_steps: int):
                   density_0=cfg.get_cfg("density0"), stiffness=cfg.get_cfg("stiffness"),
                   exponent=cfg.get_cfg("exponent"), dt=cfg.get_cfg("timeStepSize"), g=cfg.get_cfg("gravitation"),
                   simulation_method=cfg.get_cfg("simulationMethod") or 0, fluid_particle_num=sc.fluid_particle_num)
-    threads = max_threads()
+    build = "-O3 -march=native (oracle/Makefile: libsph_oracle_timing.so)"
+    try:
+        L = lib(timing=True)
+        timing = True
+    except Exception as e:      # no compiler on this host: time the parity build and say so
+        L = lib()
+        timing = False
+        build = f"-O2 -ffp-contract=off parity build (timing build failed: {type(e).__name__})"
+    threads = int(L.oracle_max_threads())
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    threads = max(1, min(threads, usable))
     o = Oracle(params, sc.arrays, n_objects=max(sc.n_objects, 1), rigid_body_ids=sorted(sc.object_id_rigid_body),
-               dynamic_ids=sorted(sc.dynamic_rigid_ids), omp_threads=threads)
+               dynamic_ids=sorted(sc.dynamic_rigid_ids), omp_threads=threads, timing_build=timing)
     o.initialize()
     o.step(1)                                   # warm-up (page faults, first sort)
-    t0 = time.perf_counter()
-    ms = o.step(sample_steps)
-    dt = time.perf_counter() - t0
+    samples, phases = [], None
+    for _ in range(max(repeats, 1)):
+        t0 = time.perf_counter()
+        ms = o.step(sample_steps)
+        samples.append(time.perf_counter() - t0)
+        phases = ms
+    samples.sort()
+    dt = samples[len(samples) // 2]
     n = sc.particle_max_num
     return {"value": round(sample_steps / dt * n / REF_PARTICLES, 4), "unit": "steps/s at 1.74M particles",
-            "cores": threads, "kind": "port",
-            "sample": f"{sample_steps} steps of the same {n}-particle workload after 1 warm-up step, "
-                      f"oracle/sph_oracle.c with {threads} OpenMP threads",
+            "cores": threads, "threads": threads, "nproc": os.cpu_count(), "kind": "port",
+            "sample": f"median of {len(samples)} samples of {sample_steps} steps of the same {n}-particle workload "
+                      f"after 1 warm-up step; oracle/sph_oracle.c, {build}, {threads} OpenMP threads",
             "ms_per_step": round(dt / sample_steps * 1e3, 2),
-            "phase_ms": {k: round(v / sample_steps, 2) for k, v in zip(("sort", "neighbour", "force", "integrate"), ms)}}
+            "samples_ms_per_step": [round(x / sample_steps * 1e3, 2) for x in samples],
+            "phase_ms": {k: round(v / sample_steps, 2) for k, v in zip(("sort", "neighbour", "force", "integrate"), phases)}}
 
 
 def main():
@@ -269,15 +290,47 @@ def main():
     dominant = max(kernels, key=lambda k_: kernels[k_][1])
     alg_bytes, dom_ms = kernels[dominant]
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    # Counter-derived figures (HBM bytes, VALU instruction counts) come from the committed rocprofv3 PMC passes
+    # (profiles/pmc_traffic.json, tools/gpu_pmc.sh + tools/refresh_pmc.py).  They are quoted ONLY when that file was
+    # measured on the kernel sources this library was built from (same fingerprint), on this workload and variant;
+    # otherwise they are null -- never a number from another revision next to a live launch time.
     traffic = valu_busy = None
-    try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (same workload / variant only)
+    pmc_k = {}
+    pmc_note = "no PMC file for this revision"
+    try:
+        from sph_taichi_amd import build as _build
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if pm["workload"] == args.workload and args.gather_impl == 1 and args.brick_shape == 0 and args.fused == 1:
-            kk = pm["kernels"][dominant]
+        if pm.get("kernel_fingerprint") != _build._fingerprint():
+            pmc_note = "profiles/pmc_traffic.json was measured on other kernel sources (fingerprint differs): not quoted"
+        elif not (pm["workload"] == args.workload and args.gather_impl == 1 and args.brick_shape == 0 and args.fused == 1
+                  and args.variant == -1 and args.settle == 0):
+            pmc_note = "profiles/pmc_traffic.json covers the default line only (workload / variant / state differ): not quoted"
+        else:
+            pmc_k = pm["kernels"]
+            kk = pmc_k[dominant]
             traffic = kk["fetch_kb"] * 1024 * 2 + kk["write_kb"] * 1024
             valu_busy = kk.get("valu_busy_frac")
-    except Exception:
-        traffic = None
+            pmc_note = f"profiles/pmc_traffic.json ({pm.get('source')}), same kernel fingerprint"
+    except Exception as e:
+        pmc_note = f"PMC file unusable ({type(e).__name__})"
+    # VALU roofline of the same kernel.  Peak issue rate: 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction
+    # (MI355X_MICROARCH.md; measured here 0.85-0.9 G wave-instructions/s per SIMD at the clock the chip sustains,
+    # profiles/r02a_ubench_valu_table1.txt -- and half / a quarter of that for the 4- and 8-cycle opcode classes).
+    # Useful work: SURVEY 8d's ~2.3 kFLOP (density) / ~4.6 kFLOP (force) per particle against 157.3 TFLOP/s.
+    VALU_PEAK_GINST = 1024 * 2.4 / 2.0
+    flop_per_particle = 2300.0 if "DENSITY" in dominant else 4600.0
+    roofline_valu = {"kernel": dominant, "unit": "G wave-instructions/s", "peak": VALU_PEAK_GINST,
+                     "peak_measured_full_rate_ops": round(1024 * 0.875, 1),
+                     "useful_tflops": round(flop_per_particle * N / (dom_ms * 1e-3) / 1e12, 2) if dom_ms > 0 else None,
+                     "peak_tflops": 157.3, "achieved": None, "frac": None, "valu_wave_insts_per_launch": None,
+                     "insts_per_particle": None, "source": pmc_note}
+    if dom_ms > 0:
+        roofline_valu["useful_frac_of_fp32_peak"] = round(roofline_valu["useful_tflops"] / 157.3, 4)
+    if pmc_k.get(dominant, {}).get("valu_wave_insts") and dom_ms > 0:
+        wi = pmc_k[dominant]["valu_wave_insts"]
+        roofline_valu.update(valu_wave_insts_per_launch=wi, achieved=round(wi / (dom_ms * 1e-3) / 1e9, 1),
+                             frac=round(wi / (dom_ms * 1e-3) / 1e9 / VALU_PEAK_GINST, 4),
+                             insts_per_particle=round(wi * 64 / N, 1))
     line = {
         "metric": "WCSPH steps/sec at 1.74 M particles (+ ms/step breakdown sort/neighbour/force)",
         "value": round(value, 3), "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -293,10 +346,12 @@ def main():
         "roofline": {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4),
-                     "valu_busy_frac": valu_busy,
-                     "note": "gather sweeps are VALU-issue-bound, not HBM-bound (DESIGN.md section 4; valu_busy_frac = share "
-                             "of SIMD cycles issuing vector ALU instructions, from the committed PMC pass); "
-                             "traffic = rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch (profiles/pmc_traffic.json)"},
+                     "valu_busy_frac": valu_busy, "counters": pmc_note,
+                     "note": "fraction of the HBM roof on ALGORITHMIC bytes, as the contract asks; the sweep itself is "
+                             "bound by VALU issue and the LDS / vector-memory pipes (roofline_valu, DESIGN.md section 4), "
+                             "so this fraction measures how far the sweep is from a pure streaming pass, not HBM "
+                             "saturation; traffic = rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch"},
+        "roofline_valu": roofline_valu,
         "roofline_kernels": {k_: {"alg_bytes": v[0], "avg_launch_ms": round(v[1], 4),
                                   "achieved_GBs": round(v[0] / (v[1] * 1e-3) / 1e9, 2) if v[1] > 0 else 0.0}
                              for k_, v in kernels.items()},

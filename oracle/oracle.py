@@ -60,19 +60,33 @@ class _State(C.Structure):
     ]
 
 
-def build(force: bool = False) -> str:
-    """Compile oracle/libsph_oracle.so with gcc (oracle/Makefile)."""
-    so = os.path.join(_HERE, "libsph_oracle.so")
+def build(force: bool = False, timing: bool = False) -> str:
+    """Compile oracle/libsph_oracle.so with gcc (oracle/Makefile).  timing=True: the -O3 -march=native build that
+    bench.py times as cpu_baseline (always rebuilt on the host it runs on; never used as a checker)."""
+    name = "libsph_oracle_timing.so" if timing else "libsph_oracle.so"
+    so = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "sph_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.run(["make", "-C", _HERE, "-s", "-B", "libsph_oracle.so"], check=True)
+    if force or timing or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-s", "-B", name], check=True)
     return so
 
 
-def lib():
-    global _LIB
+_LIB_TIMING = None
+
+
+def lib(timing: bool = False):
+    global _LIB, _LIB_TIMING
+    if timing:
+        if _LIB_TIMING is None:
+            _LIB_TIMING = _bind(C.CDLL(build(timing=True)))
+        return _LIB_TIMING
     if _LIB is None:
-        L = C.CDLL(build())
+        _LIB = _bind(C.CDLL(build()))
+    return _LIB
+
+
+def _bind(L):
+    if True:
         ps = C.POINTER(_State)
         for name in ("update_grid_id", "prefix_sum", "counting_sort", "initialize_particle_system",
                      "compute_static_boundary_volume", "compute_moving_boundary_volume",
@@ -106,8 +120,7 @@ def lib():
         L.oracle_sizeof_state.restype = C.c_int32
         L.oracle_max_threads.restype = C.c_int32
         assert L.oracle_sizeof_state() == C.sizeof(_State), "OracleState layout mismatch"
-        _LIB = L
-    return _LIB
+    return L
 
 
 def kernel_constants(support_radius: float, viscosity: float = 0.01, dim: int = 3):
@@ -132,8 +145,9 @@ class Oracle:
     """
 
     def __init__(self, params: dict, arrays: dict, n_objects: int = 1,
-                 rigid_body_ids=(), dynamic_ids=(), omp_threads: int = 1, rigid_sums_f64: bool = False):
-        L = lib()
+                 rigid_body_ids=(), dynamic_ids=(), omp_threads: int = 1, rigid_sums_f64: bool = False,
+                 timing_build: bool = False):
+        L = lib(timing=timing_build)   # timing_build: bench.py's cpu_baseline only -- never a checker
         self.L = L
         N = int(np.asarray(arrays["x"]).shape[0])
         self.N = N

@@ -42,5 +42,6 @@ class WCSPHSolver(SPHBase):
             for _ in range(n_steps):
                 self._reference_step()
             return
+        self._push()    # stiffness / exponent / viscosity / surface_tension / g are plain attributes, as in the reference
         ids, n = self._dynamic_ids()
         self.ps._call("sph_step", int(n_steps), ids, n)

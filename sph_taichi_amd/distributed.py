@@ -84,15 +84,21 @@ class LocalTransport:
 class TorchTransport:
     """torch.distributed point-to-point exchange with the x-neighbours."""
 
-    def __init__(self, device):
+    def __init__(self, device, loopback=False):
+        """`loopback` (tests): this rank is its own LEFT neighbour, so every message of the protocol -- the count
+        announcement, the record payload, the fixed-size swap -- goes through the backend's send/recv to itself.
+        That is how the RCCL path is executed on a box with one GPU."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.device = device
         self.cpu_staging = dist.get_backend() == "gloo"
+        self.loopback = bool(loopback)
 
     def _neighbours(self):
+        if self.loopback:
+            return self.rank, None
         left = self.rank - 1 if self.rank > 0 else None
         right = self.rank + 1 if self.rank < self.world - 1 else None
         return left, right
@@ -105,7 +111,9 @@ class TorchTransport:
         dev = "cpu" if self.cpu_staging else self.device
         out = {left: torch.tensor([n_left], dtype=torch.int64, device=dev),
                right: torch.tensor([n_right], dtype=torch.int64, device=dev)}
-        cin = {p: torch.zeros(1, dtype=torch.int64, device=dev) for p in (left, right) if p is not None}
+        both = torch.zeros(2, dtype=torch.int64, device=dev)     # one buffer: both counts come back in ONE device-to-host copy
+        cin = {p: both[i:i + 1] for i, p in enumerate((left, right)) if p is not None}
+        self._cin_both = both
         ops = []
         for p in (left, right):
             if p is not None:
@@ -123,7 +131,9 @@ class TorchTransport:
         self._pending = None
         for w in works:
             w.wait()
-        self._resolved = ({p: int(cnt_in[p].item()) for p in cnt_in}, announced)
+        left, right = self._neighbours()
+        vals = self._cin_both.tolist() if cnt_in else [0, 0]
+        self._resolved = ({p: int(vals[i]) for i, p in enumerate((left, right)) if p in cnt_in}, announced)
 
     def exchange(self, send_left, n_left, send_right, n_right, alloc):
         """send_* : uint8 device tensors (or None at the domain ends) holding n_* records.
@@ -239,7 +249,7 @@ class SlabSolver:
     """One rank of the slab-decomposed WCSPH solver."""
 
     def __init__(self, scene_dict, rank, world, device=0, cuts=None, capacity_factor=1.5, use_torch_stream=False,
-                 gather_impl=1, brick_shape=0, scene_dir=None, recut_every=0, nx_slack=16):
+                 gather_impl=1, brick_shape=0, scene_dir=None, recut_every=0, nx_slack=16, check_every=64):
         """`recut_every` = K > 0: every K steps the ranks add up their per-layer particle counts and every cut plane
         moves ONE cell layer towards the position that balances the particle counts (`plan_recut`); the slab may
         grow by `nx_slack` layers over its initial width before the allocation is the limit."""
@@ -271,6 +281,13 @@ class SlabSolver:
         self.recut_every = int(recut_every)
         self.width_cap = [self.cuts[i + 1] - self.cuts[i] + int(nx_slack) for i in range(world)]   # allocations
         self.steps_done = 0
+        # Conservation guard: the exchange carries HALO + 1 layers per side, i.e. it assumes that nothing moves more
+        # than one cell layer per step (CFL-sized time steps do).  A particle that does -- a violent WCSPH event, a
+        # far too large dt -- lands in the virtual cell and is truncated away, or is kept by two ranks.  Every
+        # `check_every` steps (and at every re-cut) the ranks add up their owned counts and raise if the sum is not
+        # the scene's particle count, instead of carrying on with a silently different fluid.
+        self.n_global = int(hist.sum())
+        self.check_every = int(check_every)
         self._shift = (0, 0)        # pending move of (left cut, right cut), applied at the next exchange
         self._recut_due = False
         self.ps = ParticleSystem(cfg, device=device, stream=stream, scene_dir=scene_dir,
@@ -454,6 +471,20 @@ class SlabSolver:
         if not self._recut_due:
             self.announce()
 
+    def check_conservation(self):
+        """Collective: sum of the ranks' owned counts == particles of the scene, else RuntimeError on every rank."""
+        t = self.torch.tensor([int(self.owned_range[1])], dtype=self.torch.int64, device=self.tdev)
+        total = int(self.transport.all_reduce_sum(t).item())
+        if total != self.n_global:
+            raise RuntimeError(f"slab decomposition lost particle conservation at step {self.steps_done}: the ranks own "
+                               f"{total} particles, the scene has {self.n_global} (rank {self.rank} owns {self.owned_range[1]}). "
+                               "A particle crossed more than one cell layer in a step (time step too large for the "
+                               f"flow speed?) -- the halo exchange carries {self.halo + 1} layers per side")
+
+    def _guard(self):
+        if self.check_every > 0 and (self.steps_done % self.check_every == 0 or self._recut_due):
+            self.check_conservation()
+
     def announce(self):
         if getattr(self, "transport", None) is not None and hasattr(self.transport, "start_counts"):
             self.transport.start_counts(*self.next_counts())   # the next exchange's sizes are known now
@@ -537,7 +568,7 @@ class SlabSolver:
         over ranks; ("records", packed) -> the usual record exchange, send back (rL, nL, rR, nR)."""
         ps, sv = self.ps, self.solver
         call = ps._call
-        dt = float(sv.dt[None])
+        dt = float(np.float32(sv.dt[None]))     # f32-rounded like the reference's ti.field (and like sph_dfsph_step)
         n_fluid = max(int(ps.fluid_particle_num), 1)
         rho0 = float(sv.density_0)
         first, count = self.owned_range
@@ -627,6 +658,7 @@ class SlabSolver:
                 self._recut_due = self.recut_every > 0 and (self.steps_done + 1) % self.recut_every == 0
                 self._serve(self._dfsph_step_requests())
                 self.steps_done += 1
+                self._guard()
                 if self._recut_due:
                     self.recut_now()
             return
@@ -644,6 +676,7 @@ class SlabSolver:
             t2 = time.perf_counter()
             self.phase_advance(rL, mL, rR, mR)
             self.steps_done += 1
+            self._guard()
             if self._recut_due:
                 self.recut_now()
             t3 = time.perf_counter()
@@ -702,6 +735,10 @@ def run_local_slabs(solvers, n_steps, initialize=False):
         s0 = solvers[0]
         for s in solvers:
             s.steps_done += 1
+        owned = sum(int(s.owned_range[1]) for s in solvers)      # the conservation guard of SlabSolver.step
+        if owned != s0.n_global:
+            raise RuntimeError(f"slab decomposition lost particle conservation at step {s0.steps_done}: the slabs own "
+                               f"{owned} particles, the scene has {s0.n_global}")
         if s0.recut_every > 0 and s0.steps_done % s0.recut_every == 0:
             hist = sum(s.local_histogram() for s in solvers)
             for s in solvers:
@@ -874,9 +911,13 @@ def run_slab_bench(args, rank, world, local_rank):
         "steps_per_s_job": round(steps_per_s, 3),
         "breakdown_ms": {"rank": 0, "sort": round(tm.sort_ms / kt, 4), "neighbour": round(tm.neighbour_ms / kt, 4),
                          "force": round(tm.force_ms / kt, 4), "integrate": round(tm.integrate_ms / kt, 4),
+                         "halo": round(host_ms["exchange"] / max(host_ms["steps"], 1), 4),
                          "sum_of_phases": round(tm.total_ms / kt, 4),
-                         "note": "HIP events on rank 0's stream over extra steps after the timed region; the exchange "
-                                 "runs on the host beside the interior force sweep (rank0_host_ms_per_step.exchange)"},
+                         "note": "sort / neighbour / force / integrate: HIP events on rank 0's stream over extra steps "
+                                 "after the timed region (sum_of_phases adds these four).  halo: rank 0's wall time "
+                                 "inside the record exchange per step of the timed region (batch_isend_irecv + wait); "
+                                 "it runs on the host beside the interior force sweep, so it is not an additive GPU cost "
+                                 "unless it exceeds that sweep"},
         "roofline": roofline, "cpu_baseline": None,
     }
     if dfsph:

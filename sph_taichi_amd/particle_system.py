@@ -19,10 +19,15 @@ from .field import DeviceField, HostScalar
 
 class ParticleSystem:
     def __init__(self, config: SimConfig, GGUI=False, device: int = 0, stream=None, scene_dir: str | None = None,
-                 verbose: bool = False, slab: dict | None = None):
+                 verbose: bool = False, slab: dict | None = None, populate: bool = True):
         """`slab` (multi-GPU, no reference counterpart) = dict(x_lo, x_hi, halo, capacity[, nx_slack]): this
         context owns the global cell layers [x_lo, x_hi) plus `halo` ghost layers on each side; `nx_slack` more
-        layers are allocated so that a re-cut (`set_slab_window`) can widen the slab."""
+        layers are allocated so that a re-cut (`set_slab_window`) can widen the slab.
+
+        `populate=False` stops where the reference's constructor stands after its allocations
+        (particle_system.py:91-145): every field exists with `particle_max_num` zeroed rows and
+        `particle_num[None] == 0`; the caller fills it with `add_cube` / `add_particles`, as the
+        reference's own constructor does next (:148-211)."""
         self.cfg = config
         self.GGUI = GGUI
         self.slab = slab
@@ -108,6 +113,10 @@ class ParticleSystem:
             self.color_vis_buffer = np.zeros((self.particle_max_num, 3), dtype=np.float32)
 
         # ---- upload the initial particles (the reference's _add_particles, :260-284) ----
+        if not populate:
+            if slab is not None:
+                raise ValueError("populate=False is a single-domain feature (a slab rank subsets the scene file)")
+            return              # sph_create zero-fills every array (x = 0, material 0 = solid, static), like ti.field
         for name, arr in sc.arrays.items():
             if name == "pid" and slab is None:
                 continue            # default pid = index at creation
@@ -234,11 +243,67 @@ class ParticleSystem:
         self.prefix_sum()
         self.counting_sort()
 
-    def add_cube(self, *a, **k):
-        raise NotImplementedError("particles can only be created from the scene file "
-                                  "(the reference has no emitters either, particle_system.py:85-86)")
+    def add_particles(self, object_id, new_particles_num, new_particles_positions, new_particles_velocity,
+                      new_particle_density, new_particle_pressure, new_particles_material, new_particles_is_dynamic,
+                      new_particles_color):
+        """particle_system.py:237-284: rows [particle_num, particle_num + n) of every field take the new particles
+        with add_particle's derived values (:222-235: x_0 = x, m_V = m_V0, m = m_V0 * density, acceleration left as
+        it is), then particle_num += n.  The fields are fixed-size (`particle_max_num` rows, :101-113): the
+        reference writes past their end when more is added than the scene file announced; here that raises.
+        Host-side read-modify-write of whole arrays: scene set-up, not a per-step path."""
+        n = int(new_particles_num)
+        p0 = int(self.particle_num[None])
+        if n < 0 or p0 + n > self.particle_max_num:
+            raise ValueError(f"add_particles: {p0} + {n} particles exceed particle_max_num = {self.particle_max_num} "
+                             "(the fields are sized from the scene file, particle_system.py:52-83)")
+        if n == 0:
+            return
+        if self.slab is not None:
+            raise ValueError("add_particles on a slab rank: build the scene before it is cut")
+        pos = np.asarray(new_particles_positions, dtype=np.float32).reshape(n, self.dim)
+        dens = np.asarray(new_particle_density, dtype=np.float32).reshape(n)
+        rows = {
+            "object_id": np.full(n, int(object_id), dtype=np.int32),
+            "x": pos, "x_0": pos,
+            "v": np.asarray(new_particles_velocity, dtype=np.float32).reshape(n, self.dim),
+            "density": dens,
+            "m_V": np.full(n, self.m_V0, dtype=np.float32),
+            "m": (np.float32(self.m_V0) * dens).astype(np.float32),
+            "pressure": np.asarray(new_particle_pressure, dtype=np.float32).reshape(n),
+            "material": np.asarray(new_particles_material, dtype=np.int32).reshape(n),
+            "is_dynamic": np.asarray(new_particles_is_dynamic, dtype=np.int32).reshape(n),
+            "color": np.asarray(new_particles_color, dtype=np.int32).reshape(n, 3),
+        }
+        pid = self.pid.to_numpy()
+        taken = np.zeros(self.particle_max_num, dtype=bool)
+        taken[pid[:p0]] = True
+        if taken[pid[p0:p0 + n]].any():     # (only after a sort has permuted the ids: keep them a permutation)
+            free = np.nonzero(~taken)[0][:n].astype(np.int32)
+            rest = np.setdiff1d(np.arange(self.particle_max_num, dtype=np.int32), np.concatenate([pid[:p0], free]))
+            pid[p0:p0 + n] = free
+            pid[p0 + n:] = rest
+            self.pid.from_numpy(pid)        # x_0 / color are keyed by the persistent id: set it first
+        for name, val in rows.items():
+            f = getattr(self, name)
+            a = f.to_numpy()
+            a[p0:p0 + n] = val
+            f.from_numpy(a)
+        self.particle_num[None] = p0 + n
 
-    add_particles = add_cube
+    def add_cube(self, object_id, lower_corner, cube_size, material, is_dynamic, color=(0, 0, 0), density=None,
+                 pressure=None, velocity=None):
+        """particle_system.py:458-495: a lattice of particle_diameter spacing from lower_corner (np.arange per axis,
+        'ij' meshgrid, x slowest), constant material / is_dynamic / colour / density (1000 by default) / pressure (0)
+        / velocity (0), appended through add_particles."""
+        pos = _scene.cube_positions(lower_corner, cube_size, self.particle_diameter, self.dim)
+        n = pos.shape[0]
+        vel = np.zeros_like(pos) if velocity is None else np.tile(np.asarray(velocity, dtype=np.float32), (n, 1))
+        self.add_particles(object_id, n, pos, vel,
+                           np.full(n, density if density is not None else 1000.0, dtype=np.float32),
+                           np.full(n, pressure if pressure is not None else 0.0, dtype=np.float32),
+                           np.full(n, material, dtype=np.int32), np.full(n, is_dynamic, dtype=np.int32),
+                           np.tile(np.asarray(color, dtype=np.int32), (n, 1)))
+        return n
 
     def compute_cube_particle_num(self, start, end):
         return _scene.compute_cube_particle_num(start, end, self.particle_diameter, self.dim)

@@ -89,6 +89,7 @@ class SPHBase:
 
     def _reference_step(self):
         """sph_base.py:263-271 through the individual kernels."""
+        self._push()    # the solver's knobs are plain attributes in the reference, read by every kernel: pick up any change
         self.ps.initialize_particle_system()
         self.compute_moving_boundary_volume()
         self.substep()

@@ -3,6 +3,11 @@
 mode "transport": CPU only -- TorchTransport over gloo with ragged fake record buffers.
 mode "slabs"    : needs a GPU -- every rank runs a SlabSolver on cuda:0 (gloo staging through the
                   host), rank 0 gathers positions by pid and writes them for the parent to compare.
+mode "rccl1"    : needs a GPU -- ONE rank on backend "nccl" (= RCCL on ROCm), device tensors end to end:
+                  (1) the transport protocol with the rank as its own left neighbour (count announcement, ragged
+                  record payloads, fixed-size swap: RCCL send/recv to self), (2) the 16-sum all-reduce, (3) a
+                  SlabSolver with shape-matched bodies and re-cut events stepping over TorchTransport (its
+                  all-reduces run through RCCL), positions written for the parent to compare with the single domain.
 """
 import os
 import sys
@@ -18,9 +23,46 @@ def main():
     mode, rank, world, port, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     import torch
     import torch.distributed as dist
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    if mode == "rccl1":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     from sph_taichi_amd.distributed import TorchTransport, SlabSolver, RECORD_BYTES
-    if mode == "transport":
+    if mode == "rccl1":
+        import json
+        dev = torch.device("cuda", 0)
+        assert dist.get_backend() == "nccl"
+        tr = TorchTransport(dev, loopback=True)
+        ok = True
+        for it in range(5):                  # ragged payloads, sometimes empty; counts announced one round ahead
+            n = (3 + 2 * it) % 5
+            payload = (torch.arange(max(n, 1) * RECORD_BYTES, device=dev) % 251 + it).to(torch.uint8)
+            alloc = lambda from_left, m: torch.zeros(m * RECORD_BYTES, dtype=torch.uint8, device=dev)
+            rL, mL, rR, mR = tr.exchange(payload, n, None, 0, alloc)
+            ok &= mL == n and mR == 0 and (n == 0 or bool(torch.equal(rL[: n * RECORD_BYTES], payload[: n * RECORD_BYTES])))
+            if it < 4:
+                tr.start_counts((3 + 2 * (it + 1)) % 5, 0)
+        a = torch.arange(4096, device=dev, dtype=torch.int32).view(torch.uint8)     # DFSPH ghost-velocity refresh path
+        b = torch.zeros_like(a)
+        tr.swap(a, None, b, None)
+        ok &= bool(torch.equal(a, b))
+        t = torch.arange(16, dtype=torch.float64, device=dev) * 3.0               # the bodies' 16 shape-matching sums
+        tr.all_reduce_sum(t)
+        ok &= bool(torch.equal(t.cpu(), torch.arange(16, dtype=torch.float64) * 3.0))
+        sd = json.load(open(sys.argv[6]))
+        steps = int(sys.argv[7])
+        s = SlabSolver(sd, 0, 1, device=0, recut_every=2, check_every=3)
+        s.attach(TorchTransport(dev))
+        s.initialize()
+        s.step(steps)
+        ok &= s.stats.get("recuts", 0) == 0          # one slab: every re-cut event runs its all-reduce and moves nothing
+        o = s.owned(("pid", "x", "v", "density"))
+        np.savez(out, ok=np.int32(1 if ok else 0), pid=o["pid"], x=o["x"], v=o["v"], density=o["density"],
+                 backend=np.array(dist.get_backend()))
+        s.close()
+    elif mode == "transport":
         tr = TorchTransport("cpu")
         ok = True
         cnt = lambda it: ((3 + rank + it) % 5 if rank > 0 else 0, (7 * rank + 2 * it) % 6 if rank < world - 1 else 0)

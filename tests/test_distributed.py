@@ -333,3 +333,47 @@ def test_two_gloo_ranks_on_one_gpu(tmp_path, which):
     x = np.empty_like(ref["x"])
     x[z["pid"]] = z["x"]
     assert scenes.rel_l2(x, ref["x"]) <= (2e-6 if which != "dfsph" else 1e-4)
+
+
+@pytest.mark.gpu
+def test_rccl_one_rank_transport_and_slab_solver(tmp_path):
+    """The RCCL code path on the hardware there is: one rank on backend "nccl" with device tensors end to end --
+    TorchTransport's whole protocol with the rank as its own neighbour (send/recv to self), the 16-double
+    all-reduce of the shape-matched bodies, the histogram all-reduce of the re-cut events and the conservation
+    guard's count all-reduce inside a stepping SlabSolver -- against the single-domain trajectory."""
+    sd = scenes.fluid_with_rigid_bodies(str(tmp_path / "cube.obj"))
+    steps = 12
+    ref, n = _single_domain(sd, steps)
+    scene_file = str(tmp_path / "scene.json")
+    json.dump(sd, open(scene_file, "w"))
+    out = str(tmp_path / "res.npz")
+    port = _free_port()
+    p = subprocess.Popen([sys.executable, os.path.join(HERE, "slab_worker.py"), "rccl1", "0", "1", str(port), out,
+                          scene_file, str(steps)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    try:
+        log = p.communicate(timeout=240)[0].decode()
+    except subprocess.TimeoutExpired:
+        p.kill()
+        raise AssertionError("RCCL one-rank worker hung:\n" + p.communicate()[0].decode()[-3000:])
+    assert p.returncode == 0, log[-3000:]
+    z = np.load(out)
+    assert str(z["backend"]) == "nccl" and int(z["ok"]) == 1, log[-2000:]
+    assert np.array_equal(np.sort(z["pid"]), np.arange(n))
+    x = np.empty_like(ref["x"])
+    x[z["pid"]] = z["x"]
+    assert scenes.rel_l2(x, ref["x"]) <= 2e-6
+
+
+@pytest.mark.gpu
+def test_conservation_guard_raises_when_a_particle_outruns_the_halo():
+    """a particle that crosses more than one cell layer in a step is dropped (or duplicated) by the
+    exchange; the guard must turn that into an error instead of a silently different fluid."""
+    from sph_taichi_amd.distributed import SlabSolver, run_local_slabs
+    sd = scenes.fluid_only(counts=(20, 10, 8), start=(0.1, 0.1, 0.1), velocity=(1.5, -1.0, 0.0))
+    sd["Configuration"]["timeStepSize"] = 0.05      # 1.5 m/s * 0.05 s = 0.075 m = almost two cell layers (h = 0.04) per step
+    solvers = [SlabSolver(sd, r, 2, device=0) for r in range(2)]
+    run_local_slabs(solvers, 0, initialize=True)
+    with pytest.raises(RuntimeError, match="conservation"):
+        run_local_slabs(solvers, 6)
+    for s in solvers:
+        s.close()

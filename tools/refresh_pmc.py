@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""Build profiles/pmc_traffic.json from the rocprofv3 PMC passes of tools/gpu_pmc.sh (run on the GPU box).
+
+  python tools/refresh_pmc.py gpurun_out/pmc_<tag> gpurun_out/pmc_traffic.json [--workload c3p_uniform_1.75M]
+
+Per kernel of the WCSPH step: FETCH_SIZE / WRITE_SIZE (KB per launch), SQ_INSTS_VALU (wave-level VALU instructions
+per launch), SQ_ACTIVE_INST_VALU and SQ_LDS_IDX_ACTIVE shares of the kernel's cycles.  The file carries the
+fingerprint of the kernel sources it was measured on (sph_taichi_amd.build._fingerprint()); bench.py quotes its numbers
+only while that fingerprint equals the one of the library it runs -- a stale file yields `traffic: null`.
+"""
+from __future__ import annotations
+
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+MODES = {2: "GM_DENSITY", 3: "GM_DENSITY_EOS", 6: "GM_FORCE_FUSED", 14: "GM_FORCE_FUSED_U"}
+
+
+def short_name(kernel: str) -> str:
+    m = re.search(r"k_gather_brick<\s*\(?(?:GatherMode\))?(\d+)", kernel)
+    if m:
+        return f"k_gather_brick<{MODES.get(int(m.group(1)), 'mode ' + m.group(1))}>"
+    m = re.search(r"(k_[a-z_0-9]+)", kernel)
+    return m.group(1) if m else kernel[:60]
+
+
+def main():
+    src, dst = sys.argv[1], sys.argv[2]
+    workload = sys.argv[4] if len(sys.argv) > 4 and sys.argv[3] == "--workload" else "c3p_uniform_1.75M"
+    agg = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                agg[short_name(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    from sph_taichi_amd import build
+    mean = lambda v: sum(v) / len(v) if v else None
+    kernels = {}
+    for k, c in agg.items():
+        if not k.startswith("k_") or "fillBuffer" in k:
+            continue
+        cyc = mean(c.get("GRBM_GUI_ACTIVE", []))
+        cyc = cyc / 8.0 if cyc else None          # summed over the 8 XCDs
+        e = {"dispatches": max(len(v) for v in c.values())}
+        if c.get("FETCH_SIZE"): e["fetch_kb"] = round(mean(c["FETCH_SIZE"]), 1)
+        if c.get("WRITE_SIZE"): e["write_kb"] = round(mean(c["WRITE_SIZE"]), 1)
+        if c.get("SQ_INSTS_VALU"): e["valu_wave_insts"] = round(mean(c["SQ_INSTS_VALU"]), 1)
+        if c.get("SQ_INSTS_LDS"): e["lds_wave_insts"] = round(mean(c["SQ_INSTS_LDS"]), 1)
+        if c.get("SQ_INSTS_SALU"): e["salu_wave_insts"] = round(mean(c["SQ_INSTS_SALU"]), 1)
+        if c.get("SQ_INSTS_VMEM_RD"): e["vmem_rd_wave_insts"] = round(mean(c["SQ_INSTS_VMEM_RD"]), 1)
+        if c.get("SQ_INSTS_VMEM_WR"): e["vmem_wr_wave_insts"] = round(mean(c["SQ_INSTS_VMEM_WR"]), 1)
+        if cyc:
+            e["kernel_cycles"] = round(cyc, 1)
+            if c.get("SQ_ACTIVE_INST_VALU"): e["valu_busy_frac"] = round(mean(c["SQ_ACTIVE_INST_VALU"]) * 4 / 1024 / cyc, 3)
+            if c.get("SQ_LDS_IDX_ACTIVE"): e["lds_active_frac"] = round(mean(c["SQ_LDS_IDX_ACTIVE"]) / 256 / cyc, 3)
+        if c.get("SQ_LDS_BANK_CONFLICT") and c.get("SQ_LDS_IDX_ACTIVE"):
+            e["lds_bank_conflict_share"] = round(mean(c["SQ_LDS_BANK_CONFLICT"]) / max(mean(c["SQ_LDS_IDX_ACTIVE"]), 1), 3)
+        if c.get("TCC_HIT_sum") and c.get("TCC_MISS_sum"):
+            h, m_ = mean(c["TCC_HIT_sum"]), mean(c["TCC_MISS_sum"])
+            e["l2_hit_rate"] = round(h / max(h + m_, 1), 3)
+        kernels[k] = e
+    out = {
+        "_comment": "per-launch counters from rocprofv3 PMC passes (tools/gpu_pmc.sh: each --pmc set in its own run, "
+                    "kernel-trace only). HBM bytes = FETCH_SIZE[KB]*1024*2 + WRITE_SIZE[KB]*1024 (x2 on the read side: "
+                    "gfx950 counts 128-B requests at 64 B, MI355X_MICROARCH.md; checked in round 1 on k_advect / "
+                    "k_stable_scatter). valu_busy_frac = SQ_ACTIVE_INST_VALU*4 / 1024 SIMDs / kernel cycles "
+                    "(GRBM_GUI_ACTIVE / 8 XCDs); lds_active_frac = SQ_LDS_IDX_ACTIVE / 256 CUs / kernel cycles.",
+        "kernel_fingerprint": build._fingerprint(),
+        "workload": workload,
+        "source": os.path.basename(os.path.normpath(src)),
+        "kernels": kernels,
+    }
+    os.makedirs(os.path.dirname(os.path.abspath(dst)), exist_ok=True)
+    json.dump(out, open(dst, "w"), indent=1)
+    print(json.dumps(out, indent=1)[:3000])
+
+
+if __name__ == "__main__":
+    main()

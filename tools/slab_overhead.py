@@ -17,6 +17,7 @@ ps.close()
 class NoTransport:
     def start_counts(self, a, b): self._pending = None
     def exchange(self, sL, nL, sR, nR, alloc): return None, 0, None, 0
+    def all_reduce_sum(self, t): return t
 s = SlabSolver(sd, 0, 1, device=0)
 s.attach(NoTransport()); s.initialize(); s.step(10); s.ps.sync()
 t0 = time.perf_counter(); s.step(100); s.ps.sync(); t1 = time.perf_counter()

@@ -135,6 +135,7 @@ enum SphOption {
 #define SPH_VAR_2PHASE 2   /* density: pair terms in a second loop over the lane's own list instead of inside the emission loop */
 #define SPH_VAR_MICRO 4    /* emission loop: constants in VGPRs, range-checked buffer stores (no branch, no 64-bit address) */
 #define SPH_VAR_FORCE_BF 8 /* force sweep: branch-free fluid pair term, buffer addressing for list and gather */
+#define SPH_VAR_DEEP 16    /* list-reading sweeps: list entries loaded a whole round (3 pairs) before they are decoded */
 
 /* ms accumulated by sph_step since the last sph_reset_timings (HIP events on
  * the context's stream).  sort = K1+K2+K3 (initialize_particle_system),

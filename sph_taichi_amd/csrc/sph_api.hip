@@ -193,6 +193,7 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     sph_invalidate_lists(c);
     c->opt_uniform = -1; c->uniform_state = -1; c->m_uniform = 0.0f;  // SPH_OPT_UNIFORM_FLUID: auto
     c->opt_variant = SPH_VAR_DEFAULT;
+    if (const char* e = getenv("SPH_KERNEL_VARIANT")) c->opt_variant = atoi(e) & 31;  // A/B aid: the default mask of every context of this process
     memset(&c->df_stats, 0, sizeof(c->df_stats));
     c->df.enable_divergence_solver = 1; c->df.m_max_iterations_v = 100; c->df.m_max_iterations = 100;  // DFSPH.py:12-20
     c->df.fluid_particle_num = 0; c->df.m_eps = 1e-5f; c->df.reserved_ = 0.0f; c->df.max_error_V = 0.1; c->df.max_error = 0.05;
@@ -233,7 +234,7 @@ int32_t sph_set_option(SphContext* c, int32_t option, int32_t value) {
         case SPH_OPT_SLAB_DROP_OUTSIDE: c->opt_drop_outside = value ? 1 : 0; c->uniform_state = -1; return 0;
         case SPH_OPT_SORT_BY_PID: c->opt_sort_by_pid = value ? 1 : 0; return 0;
         case SPH_OPT_KERNEL_VARIANT:
-            if (value < -1 || value > 15) return sph_fail(c, SPH_E_INVALID, "kernel variant must be -1 (default) or a mask of SPH_VAR_*");
+            if (value < -1 || value > 31) return sph_fail(c, SPH_E_INVALID, "kernel variant must be -1 (default) or a mask of SPH_VAR_*");
             c->opt_variant = value < 0 ? SPH_VAR_DEFAULT : value;
             sph_invalidate_lists(c);
             return 0;
@@ -817,7 +818,11 @@ int32_t sph_slab_forces(SphContext* c, int32_t bl_lo, int32_t bl_hi, int32_t br_
     // Boundary sets (incl. the ghost-side strips that exist when dynamic solids are force targets) in ONE launch, then
     // the two packers -- on the side stream, so the big interior sweep does not queue behind that small launch (a few
     // hundred workgroups cannot fill 256 CUs) but runs beside it.  Both sweeps write disjoint targets' accelerations.
-    static const bool no_side = getenv("SPH_NO_SIDE_STREAM") != nullptr;  // debugging aid: everything on one stream
+    static const bool no_side_env = getenv("SPH_NO_SIDE_STREAM") != nullptr;  // debugging aid: everything on one stream
+    // a rank without neighbours (world = 1, or nothing to pack and no boundary strip): no boundary launch, no packers,
+    // so no fork to the side stream and no join either
+    const bool no_boundary = bl_hi <= f_lo && br_lo >= f_hi && nL == 0 && nR == 0;
+    const bool no_side = no_side_env || no_boundary;
     if (!no_side) {
         SPH_HIP(c, hipEventRecord(c->ev_fork, c->stream));
         SPH_HIP(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
@@ -828,7 +833,7 @@ int32_t sph_slab_forces(SphContext* c, int32_t bl_lo, int32_t bl_hi, int32_t br_
     rc = rc ? rc : sphk_pack_advected(c, firstR, nR, dstR);
     c->use_side = false;
     if (rc) return rc;
-    SPH_HIP(c, hipEventRecord(c->ev_pack, no_side ? c->stream : c->side));
+    if (!no_boundary) SPH_HIP(c, hipEventRecord(c->ev_pack, no_side ? c->stream : c->side));
     // interior: overlaps with the exchange; with the one-gather sweep its finish integrates its own targets (see
     // step_sweeps), so that afterwards only the two boundary ranges -- exactly the packed ranges -- are left to advect
     // (ghost records are not advected at all: the exchange replaces them)
@@ -837,7 +842,7 @@ int32_t sph_slab_forces(SphContext* c, int32_t bl_lo, int32_t bl_hi, int32_t br_
     rc = sphk_gather_layers(c, GM_FORCE_FUSED, bl_hi, br_lo, 0, 0);
     c->fuse_advect = 0;
     if (rc) return rc;
-    SPH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pack, 0));  // the packers read what the advect overwrites
+    if (!no_boundary) SPH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pack, 0));  // the packers read what the advect overwrites
     hipEvent_t* ev = c->slab_ev_open ? c->ev[c->ev_used] : nullptr;
     if (ev) SPH_HIP(c, hipEventRecord(ev[3], c->stream));  // force = interior sweep (+ the wait for the side stream)
     if (fuse) {

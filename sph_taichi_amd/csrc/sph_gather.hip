@@ -687,6 +687,7 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
     constexpr bool V_2P = (VAR & SPH_VAR_2PHASE) != 0 && mode_inline_physics<MODE>();
     constexpr bool V_MICRO = (VAR & SPH_VAR_MICRO) != 0;
     constexpr bool V_BF = (VAR & SPH_VAR_FORCE_BF) != 0 && MODE == GM_FORCE_FUSED_U;
+    constexpr bool V_DEEP = (VAR & SPH_VAR_DEEP) != 0 && mode_reads_list<MODE>();
     constexpr bool INLINE_PHYS = mode_inline_physics<MODE>() && !V_2P;  // pair terms inside the emission loop
     float4* sQ = reinterpret_cast<float4*>(smem + CFG::OFF_Q);
     float* sW = reinterpret_cast<float*>(smem + CFG::off_w(HAS_W));  // only when HAS_W
@@ -1021,6 +1022,11 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
                 s_.A = sQ[s_.j];  // list-reading sweeps: (x, y, z, m_V)
                 if (HAS_W) s_.A.w = sW[s_.j];
                 s_.g = sColG[e >> 11] + s_.j;
+#ifdef SPH_PROFILE_FORCE
+                if ((d.ablate & 128) && mode_needs_B<MODE>()) {  // profiling build: no neighbour gather
+                    s_.B = make_float4(0.f, 0.f, 0.f, 1.0f);
+                } else
+#endif
                 if (V_BF) {
                     typedef float v4f __attribute__((ext_vector_type(4)));
                     const v4f b = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(grs, s_.g << 4, 0, 0));
@@ -1047,14 +1053,38 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
                 const int last = cnt - 1;
                 const unsigned vlast = ((unsigned)last * (unsigned)cap + (unsigned)gi) * 2u;
                 // entry `row` of this lane, clamped to its last one (row is wave-uniform: row * cap is scalar arithmetic)
+#ifdef SPH_PROFILE_FORCE
+                unsigned lde_prev = 0;  // (profiling build, ablate bit 6: only every fourth entry is loaded, the others repeat it)
+#endif
                 auto lde = [&](int row) -> unsigned {
-                    if (V_BF) return (unsigned)__builtin_amdgcn_raw_buffer_load_b16(lrs3, (int)min(((unsigned)row * (unsigned)cap + (unsigned)gi) * 2u, vlast), 0, 0);
+#ifdef SPH_PROFILE_FORCE
+                    if ((d.ablate & 64) && (row & 3)) return lde_prev;
+                    if (d.ablate & 64) return lde_prev = gl[(size_t)min(row, last) * cap];
+#endif
+                    if (V_BF || V_DEEP) return (unsigned)__builtin_amdgcn_raw_buffer_load_b16(lrs3, (int)min(((unsigned)row * (unsigned)cap + (unsigned)gi) * 2u, vlast), 0, 0);
                     return gl[(size_t)min(row, last) * cap];
                 };
                 Slot s0, s1, s2;  // three sets: the records of entries k+1 and k+2 are in flight while pair k is computed
                 unsigned ea = lde(0), eb = lde(1), ec = lde(2);
                 fetch(s0, ea);
                 fetch(s1, eb);
+                if (V_DEEP) {
+                    // The entry of pair k+3 heads a dependent chain (entry -> column table in LDS -> record gather)
+                    // and, loaded where it is decoded, has one pair's time (~300 cycles) to come back from L2.  Here
+                    // the entries of the NEXT round are loaded at the top of this one: a whole round of slack.
+                    unsigned q0 = lde(3), q1 = lde(4), q2 = lde(5);
+                    for (int k = 0; k < cnt; k += 3) {
+                        const unsigned n0 = lde(k + 6), n1 = lde(k + 7), n2 = lde(k + 8);
+                        fetch(s2, ec);
+                        pair(s0);
+                        fetch(s0, q0);
+                        if (k + 1 < cnt) pair(s1);
+                        fetch(s1, q1);
+                        ec = q2;
+                        if (k + 2 < cnt) pair(s2);
+                        q0 = n0; q1 = n1; q2 = n2;
+                    }
+                } else
                 for (int k = 0; k < cnt; k += 3) {
                     fetch(s2, ec);
                     ea = lde(k + 3);
@@ -1135,7 +1165,12 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
     hipStream_t st = sph_stream(c);
     int* blist = c->use_side ? c->brick_list2 : c->brick_list;
     int* bcount = c->use_side ? c->brick_count2 : c->brick_count;
-    if (c->use_side || !c->bricks_valid || memcmp(key, c->bricks_key, sizeof(key)) != 0) {
+    // A cached list also serves a sweep whose single target range lies INSIDE the cached one (slab mode: the force
+    // sweep over the owned layers after the density sweep over owned + first ghost layers): bricks listed for the wider
+    // range that hold no target of this sweep leave at T == 0.
+    const bool subset = c->bricks_valid && key[0] == c->bricks_key[0] && key[3] == key[4] && c->bricks_key[3] == c->bricks_key[4] &&
+                        key[1] >= c->bricks_key[1] && key[2] <= c->bricks_key[2];
+    if (c->use_side || !c->bricks_valid || (memcmp(key, c->bricks_key, sizeof(key)) != 0 && !subset)) {
         if (c->use_side || !c->brick_count_zero) SPH_HIP(c, hipMemsetAsync(bcount, 0, 2 * sizeof(int), st));
         if (!c->use_side) c->brick_count_zero = false;
         hipLaunchKernelGGL((k_brick_list<CFG>), dim3((nbricks + TPB - 1) / TPB), dim3(TPB), 0, st, d, nbx, nby, nbz, blist, bcount, c->brick_cap);
@@ -1176,7 +1211,15 @@ static int launch_brick(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, in
         }
     }
     if constexpr (MODE == GM_FORCE_FUSED_U) {
-        if (var & SPH_VAR_FORCE_BF) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_FORCE_BF>(c, lo, hi, lo2, hi2);
+        switch (var & (SPH_VAR_FORCE_BF | SPH_VAR_DEEP)) {
+            case SPH_VAR_FORCE_BF: return launch_brick_cfg<MODE, Cfg0, SPH_VAR_FORCE_BF>(c, lo, hi, lo2, hi2);
+            case SPH_VAR_DEEP: return launch_brick_cfg<MODE, Cfg0, SPH_VAR_DEEP>(c, lo, hi, lo2, hi2);
+            case SPH_VAR_FORCE_BF | SPH_VAR_DEEP: return launch_brick_cfg<MODE, Cfg0, SPH_VAR_FORCE_BF | SPH_VAR_DEEP>(c, lo, hi, lo2, hi2);
+            default: break;
+        }
+    }
+    if constexpr (MODE == GM_FORCE_FUSED) {
+        if (var & SPH_VAR_DEEP) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_DEEP>(c, lo, hi, lo2, hi2);
     }
     return launch_brick_cfg<MODE, Cfg0>(c, lo, hi, lo2, hi2);
 }
@@ -1210,7 +1253,16 @@ static int launch_df(SphContext* c) {
         if (mode_is_df_vdiv<MODE>()) c->k_kind = 0;  // density_adv changes, the walk does not refresh k_j
         return launch_simple<MODE>(c, nullptr, c->N);
     }
-    int rc = launch_brick_cfg<MODE, Cfg0>(c);
+    // SPH_OPT_KERNEL_VARIANT: the list-writing density sweep takes the padded filter + arranged emission loop (buffer
+    // offsets are 32-bit: see launch_brick).  The early entry loads of SPH_VAR_DEEP do nothing for these sweeps
+    // (DFSPH step 3.46 vs 3.51 ms with them, profiles/r02g): their pair terms gather 4 bytes, not a 16-byte record.
+    int var = c->opt_variant;
+    if ((unsigned long long)c->cap * 2ull * SPH_GLIST_ROWS >= (1ull << 32)) var &= SPH_VAR_PAD;
+    int rc;
+    if (mode_writes_list<MODE>() && (var & (SPH_VAR_PAD | SPH_VAR_MICRO)) == (SPH_VAR_PAD | SPH_VAR_MICRO))
+        rc = launch_brick_cfg<MODE, Cfg0, mode_writes_list<MODE>() ? (SPH_VAR_PAD | SPH_VAR_MICRO) : 0>(c);
+    else
+        rc = launch_brick_cfg<MODE, Cfg0>(c);
     if (!rc && mode_writes_list<MODE>()) { c->lists_valid = true; c->stg_kind = 2; c->k_kind = 0; }
     if (!rc && MODE == GM_DF_DENSITY_CHANGE) c->k_kind = 1;
     if (!rc && MODE == GM_DF_DENSITY_ADV) c->k_kind = 2;

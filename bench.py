@@ -106,12 +106,8 @@ def cpu_baseline(sd, sample_steps: int, repeats: int = 3):
         L = lib()
         timing = False
         build = f"-O2 -ffp-contract=off parity build (timing build failed: {type(e).__name__})"
-    threads = int(L.oracle_max_threads())
-    try:
-        usable = len(os.sched_getaffinity(0))
-    except AttributeError:
-        usable = os.cpu_count() or 1
-    threads = max(1, min(threads, usable))
+    from oracle.oracle import usable_cpus
+    threads = usable_cpus()          # scheduler affinity capped by the cgroup CPU quota (16 on the GPU boxes, whose nproc is 256)
     o = Oracle(params, sc.arrays, n_objects=max(sc.n_objects, 1), rigid_body_ids=sorted(sc.object_id_rigid_body),
                dynamic_ids=sorted(sc.dynamic_rigid_ids), omp_threads=threads, timing_build=timing)
     o.initialize()
@@ -127,6 +123,7 @@ def cpu_baseline(sd, sample_steps: int, repeats: int = 3):
     n = sc.particle_max_num
     return {"value": round(sample_steps / dt * n / REF_PARTICLES, 4), "unit": "steps/s at 1.74M particles",
             "cores": threads, "threads": threads, "nproc": os.cpu_count(), "kind": "port",
+            "cores_note": "cores = CPUs this container may use (affinity capped by the cgroup quota); nproc = what the host reports",
             "sample": f"median of {len(samples)} samples of {sample_steps} steps of the same {n}-particle workload "
                       f"after 1 warm-up step; oracle/sph_oracle.c, {build}, {threads} OpenMP threads",
             "ms_per_step": round(dt / sample_steps * 1e3, 2),

@@ -1121,10 +1121,10 @@ __global__ __launch_bounds__(TPB) void k_eos(DevView d) {
 // ---------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------
-typedef BrickCfg<4, 2, 4, 1792, 63> Cfg0;  // 4x2x4 cells: 1152 candidates / 256 targets at rest
-typedef BrickCfg<2, 2, 8, 1792, 63> Cfg1;  // 2x2x8 cells: 1280 candidates / 256 targets at rest
-typedef BrickCfg<2, 4, 4, 1792, 63> Cfg2;  // 2x4x4 cells
-typedef BrickCfg<2, 2, 4, 1792, 63> Cfg3;  // 2x2x4 cells:  768 candidates / 128 targets at rest
+typedef BrickCfg<4, 2, 4, 1792, 95> Cfg0;  // 4x2x4 cells: 1152 candidates / 256 targets at rest
+typedef BrickCfg<2, 2, 8, 1792, 95> Cfg1;  // 2x2x8 cells: 1280 candidates / 256 targets at rest
+typedef BrickCfg<2, 4, 4, 1792, 95> Cfg2;  // 2x4x4 cells
+typedef BrickCfg<2, 2, 4, 1792, 95> Cfg3;  // 2x2x4 cells:  768 candidates / 128 targets at rest
 
 template <int MODE>
 static int launch_simple(SphContext* c, const int* list, int n) {

@@ -79,3 +79,31 @@ def test_variants_agree_with_each_other_on_a_ragged_lattice():
         for n, tol in (("density", 2e-6), ("acceleration", 2e-5), ("x", 1e-7)):
             err = float(np.abs(got[n] - base[n]).max()) / max(float(np.abs(base[n]).max()), 1e-30)
             assert err <= tol, f"variant {variant} vs 0: {n}: {err:.3e}"
+
+
+@pytest.mark.parametrize("variant", [0, 29])
+def test_long_lists_between_64_and_95_entries(variant):
+    """A slab compressed to ~2.5 x rest density (spacing 0.74 d): 65..95 list entries per interior particle -- beyond
+    the 63 of round 1, inside LISTCAP = 95 -- so the list rows >= 64 are written by the density sweep and read back
+    by the force sweep; no target may fall back to the exact walk."""
+    from sph_taichi_amd import _lib
+    import ctypes as C
+    sd = scenes.fluid_only(counts=(14, 5, 14), start=(0.3, 0.3, 0.3), velocity=(0.2, 0.0, -0.1))
+    cfg, sc = scenes.build(sd)
+    i, j, k = np.meshgrid(np.arange(14), np.arange(5), np.arange(14), indexing="ij")
+    x = (0.3 + 0.0148 * np.stack([i, j, k], -1).reshape(-1, 3)).astype(np.float32)
+    sc.arrays["x"] = x
+    sc.arrays["x_0"] = x.copy()
+    o = scenes.make_oracle(cfg, sc)
+    ps, solver = _system(sd, sc.arrays, variant)
+    o.initialize(); solver.initialize()
+    o.step(1); solver.step(1)
+    st = _lib.SphStats()
+    ps._call("sph_get_stats", st)
+    assert 64 < st.max_list <= 95 and st.list_overflow_targets == 0 and st.lds_overflow_targets == 0, \
+        (st.max_list, st.list_overflow_targets, st.lds_overflow_targets)
+    for name, tol in (("density", 5e-5), ("acceleration", 2e-3)):
+        ref, got = o.by_pid(name), scenes.ps_by_pid(ps, name)
+        err = float(np.abs(got.astype(np.float64) - ref).max()) / max(float(np.abs(ref).max()), 1e-30)
+        assert err <= tol, f"variant {variant}: {name}: {err:.3e}"
+    ps.close()

@@ -127,7 +127,7 @@ def main():
                             "ms_per_step_all_slabs_in_lock_step_first": round(dt_first / first * 1e3, 4),
                             "ms_per_step_all_slabs_in_lock_step_rest": round(dt / max(a.steps - first, 1) * 1e3, 4),
                             "cuts_start": cuts0, "cuts_end": list(solvers[0].cuts),
-                            "recuts": int(solvers[0].stats.get("recuts", 0)),
+                            "recut_events_per_slab": [int(s.stats.get("recuts", 0)) for s in solvers],
                             "owned_start": owned0, "owned_end": owned1,
                             "imbalance_start": round(max(owned0) / (n / world), 4),
                             "imbalance_end": round(max(owned1) / (n / world), 4),

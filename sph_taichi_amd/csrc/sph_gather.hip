@@ -860,7 +860,8 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
             const unsigned vcap2 = V_MICRO ? sph_in_vgpr((unsigned)cap * 2u) : 0u;
             const float v_inv_h = V_MICRO ? sph_in_vgpr(d.inv_h) : d.inv_h, v_kw = V_MICRO ? sph_in_vgpr(d.k_w) : d.k_w;
             const float v_kw2 = V_MICRO ? sph_in_vgpr(d.k_w * 2.0f) : d.k_w * 2.0f;
-            (void)gl; (void)lrs; (void)voff; (void)vcap2; (void)v_inv_h; (void)v_kw; (void)v_kw2;
+            const float v_kw8 = V_MICRO ? sph_in_vgpr(d.k_w * 8.0f) : d.k_w * 8.0f;
+            (void)gl; (void)lrs; (void)voff; (void)vcap2; (void)v_inv_h; (void)v_kw; (void)v_kw2; (void)v_kw8;
             // phase 1: filter the 9 column runs into the private index list (4 LDS slots in flight)
             for (int dx = -1; dx <= 1; ++dx) {
                 const int nx = ix + dx;
@@ -920,10 +921,15 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
                                     const float rx = fmaf(0.5f, q4.x, txl_), ry = fmaf(0.5f, q4.y, tyl_), rz = fmaf(0.5f, q4.z, tzl_);
                                     const float r2 = rx * rx + ry * ry + rz * rz;
                                     const float qn = r2 * __builtin_amdgcn_rsqf(r2 + 1e-30f) * v_inv_h;  // r2 = 0 (self): 0 * 1e15 = 0
+                                    // sph_base.py:23-44 in one expression for both branches: with t = (1-q)+ and
+                                    // u = (1/2-q)+ the cubic spline is k (2 t^3 - 8 u^3) -- for q <= 1/2 this IS
+                                    // k (6 q^3 - 6 q^2 + 1), beyond it u = 0 leaves the outer branch, from q = 1 on t = 0.
+                                    // Two clamped FMAs replace the compare + select and the second polynomial (all
+                                    // full-rate opcodes); rounding differs from the two-branch form by ~2e-7 of W(0).
                                     const float tq = fminf(fmaxf(1.0f - qn, 0.0f), 1.0f);                // one v_fma ... clamp
-                                    const float inner = v_kw * ((6.0f * qn - 6.0f) * qn * qn + 1.0f);
-                                    const float outer = v_kw2 * (tq * tq * tq);
-                                    t.s0 += mVj * (qn <= 0.5f ? inner : outer);
+                                    const float uq = fminf(fmaxf(0.5f - qn, 0.0f), 1.0f);
+                                    const float w = v_kw2 * (tq * tq * tq) - v_kw8 * (uq * uq * uq);
+                                    t.s0 += mVj * w;
                                 }
                             }
                         } else

@@ -10,7 +10,7 @@ import scenes
 pytestmark = pytest.mark.gpu
 
 IMPLS = [(0, 0), (1, 0), (1, 1), (1, 2), (1, 3)]      # (gather_impl, brick_shape)
-F_TOL = {"m_V": 2e-5, "density": 2e-5, "pressure": 2e-3, "acceleration": 5e-4, "v": 2e-5, "x": 2e-6}
+F_TOL = {"m_V": 2e-5, "density": 2e-5, "pressure": 5e-5, "acceleration": 1e-4, "v": 2e-5, "x": 2e-6}
 
 
 def _permuted(sc, seed):
@@ -210,7 +210,7 @@ def test_random_clouds_on_awkward_grids(dom, n, seed):
         _cmp(f"density {impl},{shape}", ps.density.to_numpy(), o["density"], 3e-5)
         o.compute_non_pressure_forces(); solver.compute_non_pressure_forces()
         o.compute_pressure_forces(); solver.compute_pressure_forces()
-        _cmp(f"acc {impl},{shape}", ps.acceleration.to_numpy(), o["acceleration"], 2e-3)
+        _cmp(f"acc {impl},{shape}", ps.acceleration.to_numpy(), o["acceleration"], 2e-4)
         ps.close()
         # and the fused device loop from the same state
         o2 = Oracle(params, a, n_objects=1)
@@ -260,7 +260,7 @@ def test_shape_matched_rigid_bodies(tmp_path, impl):
 # ---------------------------------------------------------------------------
 # DFSPH (simulationMethod 4, DFSPH.py) on the same machinery
 # ---------------------------------------------------------------------------
-DF_TOL = {"density": 2e-5, "dfsph_factor": 5e-5, "density_adv": 3e-5, "acceleration": 2e-3, "v": 3e-5, "x": 2e-6}
+DF_TOL = {"density": 2e-5, "dfsph_factor": 5e-5, "density_adv": 3e-5, "acceleration": 2e-4, "v": 3e-5, "x": 2e-6}
 
 
 def _dfsph_scene(moving=True):
@@ -457,7 +457,7 @@ def test_force_paths_general_and_uniform(uniform):
     o.step(20); solver.step(20)
     assert ps.get_option(_lib.OPT_UNIFORM_FLUID_STATE) == (1 if uniform == -1 else 0)
     assert scenes.rel_l2(scenes.ps_by_pid(ps, "x"), o.by_pid("x")) <= 1e-4
-    _cmp("acceleration", scenes.ps_by_pid(ps, "acceleration"), o.by_pid("acceleration"), 2e-3)
+    _cmp("acceleration", scenes.ps_by_pid(ps, "acceleration"), o.by_pid("acceleration"), 2e-4)
     ps.close()
 
 

@@ -100,13 +100,15 @@ def analyse(x, h, label, BX=4, BY=2, BZ=4, margin=1.0002):
                     res["mirrored"] += int(M.max(0).sum())
                     res["sorted"] += int((-np.sort(-H, axis=1)).max(0).sum())
                     res["merged"] += int(H.sum(1).max())
+                    # antipodal pairs emitted jointly: (dx,dy) with (-dx,-dy), centre alone
+                    res["paired"] = res.get("paired", 0) + int(sum((H[:, a] + H[:, 8 - a]).max() for a in range(4)) + H[:, 4].max())
                     res["ideal"] += float(H.sum(1).mean())
                     res["filt_nat"] += int((((rlen[ids] + 7) // 8) * 8).max(0).sum())
                     res["waves"] += 1
     w = max(res["waves"], 1)
     print(f"{label}: {N} particles, mean cell occupancy {cnt[cnt > 0].mean():.2f} (max {cnt.max()}), {w} interior waves")
     print(f"   mean hits per lane {res['ideal'] / w:.1f};  emission trips per wave: natural {res['natural'] / w:.1f}, "
-          f"mirrored {res['mirrored'] / w:.1f}, sorted {res['sorted'] / w:.1f}, merged {res['merged'] / w:.1f};  "
+          f"mirrored {res['mirrored'] / w:.1f}, antipodal pairs {res.get('paired', 0) / w:.1f}, sorted {res['sorted'] / w:.1f}, merged {res['merged'] / w:.1f};  "
           f"filter candidates per wave (lock-step, 8 per trip) {res['filt_nat'] / w:.0f}")
     return res
 

@@ -334,13 +334,15 @@ __device__ __forceinline__ void pair_force_u_bf(const DevView& d, Target& t, flo
     const float rinv = __builtin_amdgcn_rsqf(r2 + 1e-30f);
     const float rn = r2 * rinv;
     const float q = rn * d.inv_h;
+    // sph_base.py:23-68 without branches: with t = (1-q)+ and u = (1/2-q)+,  W = k (2 t^3 - 8 u^3)  and
+    // dW/dq = 6k (4 u^2 - t^2)  reproduce both pieces of the cubic spline and vanish from q = 1 on.
     const float f = fminf(fmaxf(1.0f - q, 0.0f), 1.0f);
-    const float cin = d.k_dw * q * (3.0f * q - 2.0f), cout = d.k_dw * (-f * f);  // sph_base.py:46-68
-    const float cg = q <= 0.5f ? cin : cout;
+    const float u = fminf(fmaxf(0.5f - q, 0.0f), 1.0f);
+    const float f2 = f * f, u2 = u * u;
+    const float cg = d.k_dw * (4.0f * u2 - f2);
     const float gc = rn > 1e-5f ? cg * (rinv * d.inv_h) : 0.0f;
     if (A.w > 0.0f) {
-        const float win = d.k_w * ((6.0f * q - 6.0f) * q * q + 1.0f), wout = d.k_w * 2.0f * (f * f * f);  // sph_base.py:23-44
-        const float wq = q <= 0.5f ? win : wout;
+        const float wq = d.k_w * 2.0f * (f2 * f) - d.k_w * 8.0f * (u2 * u);
         const float w = (r2 > d.d2) ? wq : d.w_d;
         const float c = t.st_c * w;                                               // WCSPH.py:93-102
         const float v_xy = (t.vx - B.x) * rx + (t.vy - B.y) * ry + (t.vz - B.z) * rz;

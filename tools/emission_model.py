@@ -38,7 +38,7 @@ def settle(n, steps, threads):
     return x0, o.by_pid("x").copy(), sc.geom
 
 
-def analyse(x, h, label, BX=4, BY=2, BZ=4, margin=1.0002):
+def analyse(x, h, label, BX=4, BY=2, BZ=4, margin=1.0002, sort_cells=False):
     cell = np.floor(x / h).astype(np.int64)
     lo = cell.min(0)
     cell -= lo
@@ -80,13 +80,19 @@ def analyse(x, h, label, BX=4, BY=2, BZ=4, margin=1.0002):
         for by in bys:
             for bz in bzs:
                 t = []
+                cells = []
                 for ix in range(bx * BX, bx * BX + BX):
                     for iy in range(by * BY, by * BY + BY):
                         k0 = (ix * ny + iy) * nz + bz * BZ
                         t.extend(range(beg[k0], end[k0 + BZ - 1]))
+                        cells.extend(range(k0, k0 + BZ))
                 t = np.array(t, np.int64)
                 if len(t) < 64:
                     continue
+                if sort_cells:      # lanes assigned cell by cell in order of the cell's candidate count (longest runs first)
+                    work = [int(rlen[beg[c]].sum()) if cnt[c] else 0 for c in cells]
+                    order_c = sorted(range(len(cells)), key=lambda q: -work[q])
+                    t = np.array([p_ for q in order_c for p_ in range(beg[cells[q]], end[cells[q]])], np.int64)
                 for w in range(0, len(t) - 63, 64):
                     ids = t[w:w + 64]
                     H = hits[ids]
@@ -122,8 +128,10 @@ def main():
     x0, x1, geom = settle(a.n, a.steps, a.threads)
     h = geom.support_radius if hasattr(geom, "support_radius") else 4 * geom.particle_radius
     analyse(x0.astype(np.float64), h, "rest lattice")
+    analyse(x0.astype(np.float64), h, "rest lattice, lanes by cell workload", sort_cells=True)
     if a.steps:
         analyse(x1.astype(np.float64), h, f"after {a.steps} steps")
+        analyse(x1.astype(np.float64), h, f"after {a.steps} steps, lanes by cell workload", sort_cells=True)
 
 
 if __name__ == "__main__":

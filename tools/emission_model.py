@@ -55,6 +55,7 @@ def analyse(x, h, label, BX=4, BY=2, BZ=4, margin=1.0002, sort_cells=False):
     N = len(x)
     # per target: hits per run [9] in natural (dx, dy) order, run lengths [9]
     hits = np.zeros((N, 9), np.int32)
+    hits_c = np.zeros((N, 9, 4), np.int32)     # hits per 32-candidate chunk of the run (the kernel's mask registers)
     rlen = np.zeros((N, 9), np.int32)
     for r, (dx, dy) in enumerate((a, b) for a in (-1, 0, 1) for b in (-1, 0, 1)):
         cx = cell[:, 0] + dx; cy = cell[:, 1] + dy
@@ -69,7 +70,9 @@ def analyse(x, h, label, BX=4, BY=2, BZ=4, margin=1.0002, sort_cells=False):
             m = k < L
             j = np.where(m, b + k, 0)
             dd = x - x[j]
-            hits[:, r] += (m & ((dd * dd).sum(1) < h2)).astype(np.int32)
+            hit = (m & ((dd * dd).sum(1) < h2)).astype(np.int32)
+            hits[:, r] += hit
+            hits_c[:, r, min(k // 32, 3)] += hit
     # interior targets only (full neighbourhoods), grouped into bricks then waves of 64 consecutive targets
     sx = frac[:, 0] >= 0.5; sy = frac[:, 1] >= 0.5
     perm_nat = np.arange(9)
@@ -97,6 +100,7 @@ def analyse(x, h, label, BX=4, BY=2, BZ=4, margin=1.0002, sort_cells=False):
                     ids = t[w:w + 64]
                     H = hits[ids]
                     res["natural"] += int(H.max(0).sum())
+                    res["chunked"] = res.get("chunked", 0) + int(hits_c[ids].max(0).sum())
                     # mirrored: phase (px, py) -> run (sx ? 2-px : px, sy ? 2-py : py)
                     M = np.empty_like(H)
                     for p in range(9):
@@ -113,7 +117,7 @@ def analyse(x, h, label, BX=4, BY=2, BZ=4, margin=1.0002, sort_cells=False):
                     res["waves"] += 1
     w = max(res["waves"], 1)
     print(f"{label}: {N} particles, mean cell occupancy {cnt[cnt > 0].mean():.2f} (max {cnt.max()}), {w} interior waves")
-    print(f"   mean hits per lane {res['ideal'] / w:.1f};  emission trips per wave: natural {res['natural'] / w:.1f}, "
+    print(f"   mean hits per lane {res['ideal'] / w:.1f};  emission trips per wave: per 32-candidate chunk (the kernel) {res.get('chunked', 0) / w:.1f}, per run {res['natural'] / w:.1f}, "
           f"mirrored {res['mirrored'] / w:.1f}, antipodal pairs {res.get('paired', 0) / w:.1f}, sorted {res['sorted'] / w:.1f}, merged {res['merged'] / w:.1f};  "
           f"filter candidates per wave (lock-step, 8 per trip) {res['filt_nat'] / w:.0f}")
     return res

@@ -91,7 +91,9 @@ __device__ __forceinline__ float4 make_C_from_aux(const float4 aux) {
 // E = the target's own aux (stand-alone force modes) or eos (fused force) record, loaded by the caller
 template <int MODE>
 __device__ __forceinline__ float4 target_load_E(const DevView& d, int i) {
-    if (MODE == GM_NONPRESSURE || MODE == GM_PRESSURE) return d.aux[i];
+    // (GM_DENSITY_EOS: the aux record its finish rewrites -- requested with the target's other records, so that the
+    // finish does not end every brick with a load it has to wait for)
+    if (MODE == GM_NONPRESSURE || MODE == GM_PRESSURE || MODE == GM_DENSITY_EOS) return d.aux[i];
     if (MODE == GM_FORCE_FUSED || MODE == GM_FORCE_FUSED_U || mode_is_df_iter<MODE>() || mode_is_df_vdiv<MODE>() ||
         MODE == GM_DF_NONPRESSURE)
         return d.eos[i];
@@ -367,7 +369,7 @@ __device__ __forceinline__ void pair_force_u_bf(const DevView& d, Target& t, flo
 
 // write-back of one particle (target or not) for the given mode
 template <int MODE>
-__device__ __forceinline__ void target_finish(const DevView& d, Target& t, int i, bool gathered) {
+__device__ __forceinline__ void target_finish(const DevView& d, Target& t, int i, bool gathered, const float4 E = make_float4(0.f, 0.f, 0.f, 0.f)) {
     if (MODE == GM_BVOL_STATIC || MODE == GM_BVOL_DYNAMIC) {
         // sph_base.py:98, 113: m_V = 1/delta * 3.0   (only .w is written; .xyz are read concurrently)
         if (gathered) reinterpret_cast<float*>(&d.xm[i])[3] = 1.0f / t.s0 * 3.0f;
@@ -379,7 +381,7 @@ __device__ __forceinline__ void target_finish(const DevView& d, Target& t, int i
         return;
     }
     if (MODE == GM_DENSITY_EOS) {
-        float4 aux = d.aux[i];
+        float4 aux = E;  // = d.aux[i], loaded by the caller (target_load_E)
         float4 e;
         if (gathered) {
             float rho_raw = (t.self_in_sum ? t.s0 : t.mV * d.w_zero + t.s0) * d.rho0;  // WCSPH.py:39-43
@@ -540,10 +542,11 @@ __global__ __launch_bounds__(TPB) void k_gather_simple(DevView d, const int* __r
     Target t;
     const float4 A = d.xm[i];
     const float4 B = d.vf[i];
-    target_init<MODE>(d, t, A, B, target_load_E<MODE>(d, i));
+    const float4 E = target_load_E<MODE>(d, i);
+    target_init<MODE>(d, t, A, B, E);
     const bool g = target_gathers<MODE>(t.flags);
     if (g) gather_walk_global<MODE>(d, t, i);
-    target_finish<MODE>(d, t, i, g);
+    target_finish<MODE>(d, t, i, g, E);
 }
 
 // Boundary volume of a short target list (the dynamic rigid particles, every step): one target per 16 lanes, lane r
@@ -678,8 +681,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sph_rsrc(const void* p, unsign
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
+// second launch bound = waves per SIMD the LDS tile allows anyway (four workgroups per CU for the filtering sweeps, five
+// for the list-reading ones): the register allocator must not go past 128 / 96 VGPRs, or a resident slot is lost
 template <int MODE, class CFG, int VAR = 0>
-__global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nbz, const int* __restrict__ brick_list,
+__global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gather_brick(DevView d, int nby, int nbz, const int* __restrict__ brick_list,
                                                       const int* __restrict__ brick_count,
                                                       unsigned short* __restrict__ glist,
                                                       unsigned char* __restrict__ gcnt, int cap, int list_cap) {
@@ -1110,7 +1115,7 @@ __global__ __launch_bounds__(TPB) void k_gather_brick(DevView d, int nby, int nb
             target_init<mode_walk<MODE>()>(d, t, Ai, Bi, Ei);
             gather_walk_global<mode_walk<MODE>()>(d, t, gi);
         }
-        target_finish<MODE>(d, t, gi, g);
+        target_finish<MODE>(d, t, gi, g, Ei);
     }
     }
 }

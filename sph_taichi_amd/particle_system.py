@@ -274,15 +274,8 @@ class ParticleSystem:
             "is_dynamic": np.asarray(new_particles_is_dynamic, dtype=np.int32).reshape(n),
             "color": np.asarray(new_particles_color, dtype=np.int32).reshape(n, 3),
         }
-        pid = self.pid.to_numpy()
-        taken = np.zeros(self.particle_max_num, dtype=bool)
-        taken[pid[:p0]] = True
-        if taken[pid[p0:p0 + n]].any():     # (only after a sort has permuted the ids: keep them a permutation)
-            free = np.nonzero(~taken)[0][:n].astype(np.int32)
-            rest = np.setdiff1d(np.arange(self.particle_max_num, dtype=np.int32), np.concatenate([pid[:p0], free]))
-            pid[p0:p0 + n] = free
-            pid[p0 + n:] = rest
-            self.pid.from_numpy(pid)        # x_0 / color are keyed by the persistent id: set it first
+        # (the persistent id of a new row is the id that row already holds: pid is a permutation of the rows at all
+        # times -- identity before the first sort -- so x_0 / colour, which are keyed by it, land where the row reads them)
         for name, val in rows.items():
             f = getattr(self, name)
             a = f.to_numpy()

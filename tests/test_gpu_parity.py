@@ -557,3 +557,4 @@ def test_scene_built_through_add_cube_and_add_particles_equals_the_json_scene(tm
     # between two runs are possible, so the trajectories are compared with a tolerance rather than bit for bit)
     assert scenes.rel_l2(scenes.ps_by_pid(ps, "x"), scenes.ps_by_pid(ref_ps, "x")) <= 1e-6
     ps.close(); ref_ps.close()
+

@@ -10,7 +10,7 @@
 //                    the cell (one returning atomic per RUN of equal cells in
 //                    a wave -- particles arrive almost sorted, so ~8x fewer
 //                    atomics than one per particle)
-//   scan           : cell_end = inclusive prefix (3 launches, wave64 shuffles)
+//   scan           : cell_end = inclusive prefix (2 launches, wave64 shuffles; each tile adds up the totals before it)
 //   unstable_place : idx_unstable[start(c)+off[i]] = i
 //   stable_scatter : rank of i among its cell's members by previous index,
 //                    then move the 48-byte hot record (ping-pong, no copy-back)
@@ -83,34 +83,6 @@ __global__ __launch_bounds__(TPB) void k_scan_reduce(const int4* __restrict__ da
     if (threadIdx.x == 0) sums[blockIdx.x] = tot;
 }
 
-// one block: exclusive scan of the per-tile sums
-__global__ __launch_bounds__(1024) void k_scan_sums(int* __restrict__ sums, int n) {
-    __shared__ int s_wave[16];
-    __shared__ int s_carry;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int v = i < n ? sums[i] : 0;
-        const int incl = sph_wave_inclusive_scan(v, lane);
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        int wave_off = 0, tot = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            const int s = s_wave[w];
-            if (w < wave) wave_off += s;
-            tot += s;
-        }
-        const int carry = s_carry;
-        if (i < n) sums[i] = carry + wave_off + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 0) s_carry = carry + tot;
-        __syncthreads();
-    }
-}
-
 __global__ __launch_bounds__(TPB) void k_scan_apply(int4* __restrict__ data, const int* __restrict__ sums) {
     __shared__ int s_wave[TPB / 64];
     const int base = (blockIdx.x * TPB + threadIdx.x) * (SCAN_IPT / 4);
@@ -121,8 +93,15 @@ __global__ __launch_bounds__(TPB) void k_scan_apply(int4* __restrict__ data, con
         v[k] = data[base + k];
         t += v[k].x + v[k].y + v[k].z + v[k].w;
     }
-    int tot;
-    int run = sums[blockIdx.x] + block_exclusive_offset(t, s_wave, tot);
+    // The tile's offset = sum of the totals of the tiles before it: each block adds them up itself (a few hundred
+    // L2-resident integers spread over its 256 lanes) -- there is no separate one-block launch that scans the totals,
+    // and a launch between two dependent kernels costs ~5 us here whatever it does.
+    int before = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += TPB) before += sums[j];
+    int tot, before_tot;
+    (void)block_exclusive_offset(before, s_wave, before_tot);
+    __syncthreads();  // s_wave is reused
+    int run = before_tot + block_exclusive_offset(t, s_wave, tot);
 #pragma unroll
     for (int k = 0; k < SCAN_IPT / 4; ++k) {
         run += v[k].x; v[k].x = run;
@@ -203,8 +182,6 @@ int sphk_hash_histogram(SphContext* c) {
 int sphk_scan(SphContext* c) {
     const int nb = c->scan_blocks;
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(TPB), 0, c->stream, (const int4*)c->cell_end, c->scan_sums);
-    SPH_LAUNCH_CHECK(c);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, c->stream, c->scan_sums, nb);
     SPH_LAUNCH_CHECK(c);
     hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(TPB), 0, c->stream, (int4*)c->cell_end, c->scan_sums);
     SPH_LAUNCH_CHECK(c);

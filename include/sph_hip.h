@@ -136,6 +136,7 @@ enum SphOption {
 #define SPH_VAR_MICRO 4    /* emission loop: constants in VGPRs, range-checked buffer stores (no branch, no 64-bit address) */
 #define SPH_VAR_FORCE_BF 8 /* force sweep: branch-free fluid pair term, buffer addressing for list and gather */
 #define SPH_VAR_DEEP 16    /* list-reading sweeps: list entries loaded a whole round (3 pairs) before they are decoded */
+#define SPH_VAR_MIRROR 32  /* density (with PAD | MICRO): all nine runs filtered first, hits emitted near side first */
 
 /* ms accumulated by sph_step since the last sph_reset_timings (HIP events on
  * the context's stream).  sort = K1+K2+K3 (initialize_particle_system),

@@ -693,6 +693,7 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
     constexpr bool V_PAD = (VAR & SPH_VAR_PAD) != 0;
     constexpr bool V_2P = (VAR & SPH_VAR_2PHASE) != 0 && mode_inline_physics<MODE>();
     constexpr bool V_MICRO = (VAR & SPH_VAR_MICRO) != 0;
+    constexpr bool V_MIRROR = (VAR & SPH_VAR_MIRROR) != 0 && V_PAD && V_MICRO;
     constexpr bool V_BF = (VAR & SPH_VAR_FORCE_BF) != 0 && MODE == GM_FORCE_FUSED_U;
     constexpr bool V_DEEP = (VAR & SPH_VAR_DEEP) != 0 && mode_reads_list<MODE>();
     constexpr bool INLINE_PHYS = mode_inline_physics<MODE>() && !V_2P;  // pair terms inside the emission loop
@@ -869,6 +870,107 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
             const float v_kw2 = V_MICRO ? sph_in_vgpr(d.k_w * 2.0f) : d.k_w * 2.0f;
             const float v_kw8 = V_MICRO ? sph_in_vgpr(d.k_w * 8.0f) : d.k_w * 8.0f;
             (void)gl; (void)lrs; (void)voff; (void)vcap2; (void)v_inv_h; (void)v_kw; (void)v_kw2; (void)v_kw8;
+// Hits are collected in a per-run bitmask register (no LDS traffic while filtering) and turned into list
+// entries once per chunk of <= 32 candidates: ~7 ds_write per run instead of one per candidate.
+// One candidate = 3 FMA + 1 add + 1 v_alignbit: the test value r2' - thr' is negative for a hit, and alignbit shifts
+// its SIGN BIT into the mask ((mask << 1) | sign) -- no compare, no select.  A chunk is walked from its last candidate
+// to its first, so candidate k ends up at bit k and the hits come out in ascending order with ffs / clear-lowest-bit.
+#define SPH_ACC(Q_) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(fmaf(txl_, (Q_).x, fmaf(tyl_, (Q_).y, fmaf(tzl_, (Q_).z, (Q_).w - thr)))), 31)
+            // hit mask of the n <= 32 candidates from LDS slot `base` on (n >= 1)
+            auto filter_chunk = [&](int base, int n) -> unsigned {
+                unsigned mask = 0;
+                // V_PAD: whole groups of 8 only.  Up to 7 records past the run's end are tested too (they are
+                // the next run's, or the first bytes of the m_V array behind the last record: always inside
+                // this workgroup's LDS) and their bits are cleared afterwards -- 7 wasted tests at 5 VALU each
+                // instead of up to 7 one-candidate trips that each wait for their own ds_read.
+                int k = V_PAD ? ((n + 7) & ~7) : n;
+                if (!V_PAD) {
+                    while (k & 7) {  // the ragged end first
+                        --k;
+                        const float4 q0 = sQ[base + k];
+                        SPH_ACC(q0);
+                    }
+                }
+                while (k > 0) {
+                    k -= 8;
+                    const float4* q = &sQ[base + k];
+                    const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                    const float4 q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7];
+                    SPH_ACC(q7); SPH_ACC(q6); SPH_ACC(q5); SPH_ACC(q4);
+                    SPH_ACC(q3); SPH_ACC(q2); SPH_ACC(q1); SPH_ACC(q0);
+                }
+                if (V_PAD) mask &= 0xffffffffu >> (32 - n);
+                if (d.ablate & 16) mask &= (d.ablate >> 8);  // profiling: filter only (mask kept live, no hit emitted)
+                return mask;
+            };
+#undef SPH_ACC
+            // V_MICRO: the hits of one mask become list entries `tagbase + bit` and (inline sweeps) density terms
+            auto emit_micro = [&](unsigned mask, unsigned tagbase, unsigned base16) {
+                cnt += __popc(mask);
+                while (mask) {
+                    const unsigned bit = (unsigned)__ffs((int)mask) - 1u;
+                    mask &= mask - 1u;
+                    if (!(d.ablate & 2)) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(tagbase + bit), lrs, (int)voff, 0, 0);
+                    voff += vcap2;
+                    if (INLINE_PHYS && !(d.ablate & 32)) {  // the pair term of the legacy loop below, addresses and constants arranged for the issue rates
+                        const unsigned aq = base16 + (bit << 4);
+                        const float4 q4 = *reinterpret_cast<const float4*>(smem + CFG::OFF_Q + aq);
+                        const float mVj = *reinterpret_cast<const float*>(smem + CFG::off_w(true) + (aq >> 2));
+                        const float rx = fmaf(0.5f, q4.x, txl_), ry = fmaf(0.5f, q4.y, tyl_), rz = fmaf(0.5f, q4.z, tzl_);
+                        const float r2 = rx * rx + ry * ry + rz * rz;
+                        const float qn = r2 * __builtin_amdgcn_rsqf(r2 + 1e-30f) * v_inv_h;  // r2 = 0 (self): 0 * 1e15 = 0
+                        // sph_base.py:23-44 in one expression for both branches: with t = (1-q)+ and
+                        // u = (1/2-q)+ the cubic spline is k (2 t^3 - 8 u^3) -- for q <= 1/2 this IS
+                        // k (6 q^3 - 6 q^2 + 1), beyond it u = 0 leaves the outer branch, from q = 1 on t = 0.
+                        // Two clamped FMAs replace the compare + select and the second polynomial (all
+                        // full-rate opcodes); rounding differs from the two-branch form by ~2e-7 of W(0).
+                        const float tq = fminf(fmaxf(1.0f - qn, 0.0f), 1.0f);                // one v_fma ... clamp
+                        const float uq = fminf(fmaxf(0.5f - qn, 0.0f), 1.0f);
+                        const float w = v_kw2 * (tq * tq * tq) - v_kw8 * (uq * uq * uq);
+                        t.s0 += mVj * w;
+                    }
+                }
+            };
+            if (V_MIRROR) {
+                // SPH_VAR_MIRROR: filter all nine runs first (their first 32 candidates: one mask and one tag|base per
+                // run stay in registers; longer runs emit their further chunks at once), then emit NEAR SIDE FIRST:
+                // a target in the upper half of its cell along x walks dx = +1, 0, -1 instead of -1, 0, +1, likewise
+                // y.  A lane's hits sit mostly in the runs on its near side, so in the natural order lanes of
+                // opposite halves make every run's loop as long as the busier half needs; mirrored, the lanes of a
+                // wave are busy in the same phases (tools/emission_model.py: 109 -> 81 trips per wave in a settled flow).
+                unsigned mk[9], tk[9];
+#pragma unroll
+                for (int r = 0; r < 9; ++r) {
+                    const int nx = ix + r / 3 - 1, ny = iy + r % 3 - 1;
+                    const bool ok = nx >= 0 && nx < d.nx && ny >= 0 && ny < d.ny;
+                    const int ncol = ok ? (nx - sx0) * ncy + (ny - sy0) : 0;
+                    const int rel = -sColG[ncol];
+                    const int lo = sCE[ncol * CFG::NZS + klo] + rel;
+                    const int hi = ok ? sCE[ncol * CFG::NZS + khi + 1] + rel : lo;
+                    const int n = min(32, hi - lo);
+                    mk[r] = n > 0 ? filter_chunk(lo, n) : 0u;
+                    tk[r] = ((unsigned)ncol << 11) | (unsigned)lo;
+                }
+                for (int r = 0; r < 9; ++r) {  // (rare) chunks beyond the first 32 candidates of a run
+                    const int nx = ix + r / 3 - 1, ny = iy + r % 3 - 1;
+                    if (nx < 0 || nx >= d.nx || ny < 0 || ny >= d.ny) continue;
+                    const int ncol = (nx - sx0) * ncy + (ny - sy0);
+                    const int rel = -sColG[ncol];
+                    const int lo = sCE[ncol * CFG::NZS + klo] + rel, hi = sCE[ncol * CFG::NZS + khi + 1] + rel;
+                    for (int base = lo + 32; base < hi; base += 32)
+                        emit_micro(filter_chunk(base, min(32, hi - base)), ((unsigned)ncol << 11) | (unsigned)base, (unsigned)base << 4);
+                }
+                const float half = 0.5f * d.grid_size;
+                const bool sxh = txl_ - (float)(ix - sx0) * d.grid_size >= half, syh = tyl_ - (float)(iy - sy0) * d.grid_size >= half;
+#pragma unroll
+                for (int p = 0; p < 9; ++p) {
+                    const int px = p / 3, py = p % 3;
+                    const int ra = px * 3 + py, rb = (2 - px) * 3 + py, rc = px * 3 + (2 - py), rd = (2 - px) * 3 + (2 - py);
+                    const unsigned m_ = syh ? (sxh ? mk[rd] : mk[rc]) : (sxh ? mk[rb] : mk[ra]);
+                    const unsigned t_ = syh ? (sxh ? tk[rd] : tk[rc]) : (sxh ? tk[rb] : tk[ra]);
+                    emit_micro(m_, t_, (t_ & 2047u) << 4);
+                }
+            } else
             // phase 1: filter the 9 column runs into the private index list (4 LDS slots in flight)
             for (int dx = -1; dx <= 1; ++dx) {
                 const int nx = ix + dx;
@@ -881,64 +983,12 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                     const int lo = sCE[ncol * CFG::NZS + klo] + rel;
                     const int hi = sCE[ncol * CFG::NZS + khi + 1] + rel;
                     const unsigned tag = (unsigned)ncol << 11;
-// Hits are collected in a per-run bitmask register (no LDS traffic while filtering) and turned into list
-// entries once per chunk of <= 32 candidates: ~7 ds_write per run instead of one per candidate.
-// One candidate = 3 FMA + 1 add + 1 v_alignbit: the test value r2' - thr' is negative for a hit, and alignbit shifts
-// its SIGN BIT into the mask ((mask << 1) | sign) -- no compare, no select.  A chunk is walked from its last candidate
-// to its first, so candidate k ends up at bit k and the hits come out in ascending order with ffs / clear-lowest-bit.
-#define SPH_ACC(Q_) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(fmaf(txl_, (Q_).x, fmaf(tyl_, (Q_).y, fmaf(tzl_, (Q_).z, (Q_).w - thr)))), 31)
                     for (int base = lo; base < hi; base += 32) {
                         const int n = min(32, hi - base);
-                        unsigned mask = 0;
-                        // V_PAD: whole groups of 8 only.  Up to 7 records past the run's end are tested too (they are
-                        // the next run's, or the first bytes of the m_V array behind the last record: always inside
-                        // this workgroup's LDS) and their bits are cleared afterwards -- 7 wasted tests at 5 VALU each
-                        // instead of up to 7 one-candidate trips that each wait for their own ds_read.
-                        int k = V_PAD ? ((n + 7) & ~7) : n;
-                        if (!V_PAD) {
-                            while (k & 7) {  // the ragged end first
-                                --k;
-                                const float4 q0 = sQ[base + k];
-                                SPH_ACC(q0);
-                            }
-                        }
-                        while (k > 0) {
-                            k -= 8;
-                            const float4* q = &sQ[base + k];
-                            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-                            const float4 q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7];
-                            SPH_ACC(q7); SPH_ACC(q6); SPH_ACC(q5); SPH_ACC(q4);
-                            SPH_ACC(q3); SPH_ACC(q2); SPH_ACC(q1); SPH_ACC(q0);
-                        }
-                        if (V_PAD) mask &= 0xffffffffu >> (32 - n);
-                        if (d.ablate & 16) mask &= (d.ablate >> 8);  // profiling: filter only (mask kept live, no hit emitted)
+                        unsigned mask = filter_chunk(base, n);
                         const unsigned tagbase = tag | (unsigned)base;
                         if (V_MICRO) {
-                            const unsigned base16 = (unsigned)base << 4;
-                            cnt += __popc(mask);
-                            while (mask) {
-                                const unsigned bit = (unsigned)__ffs((int)mask) - 1u;
-                                mask &= mask - 1u;
-                                if (!(d.ablate & 2)) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(tagbase + bit), lrs, (int)voff, 0, 0);
-                                voff += vcap2;
-                                if (INLINE_PHYS && !(d.ablate & 32)) {  // the same pair term as below, addresses and constants arranged for the issue rates
-                                    const unsigned aq = base16 + (bit << 4);
-                                    const float4 q4 = *reinterpret_cast<const float4*>(smem + CFG::OFF_Q + aq);
-                                    const float mVj = *reinterpret_cast<const float*>(smem + CFG::off_w(true) + (aq >> 2));
-                                    const float rx = fmaf(0.5f, q4.x, txl_), ry = fmaf(0.5f, q4.y, tyl_), rz = fmaf(0.5f, q4.z, tzl_);
-                                    const float r2 = rx * rx + ry * ry + rz * rz;
-                                    const float qn = r2 * __builtin_amdgcn_rsqf(r2 + 1e-30f) * v_inv_h;  // r2 = 0 (self): 0 * 1e15 = 0
-                                    // sph_base.py:23-44 in one expression for both branches: with t = (1-q)+ and
-                                    // u = (1/2-q)+ the cubic spline is k (2 t^3 - 8 u^3) -- for q <= 1/2 this IS
-                                    // k (6 q^3 - 6 q^2 + 1), beyond it u = 0 leaves the outer branch, from q = 1 on t = 0.
-                                    // Two clamped FMAs replace the compare + select and the second polynomial (all
-                                    // full-rate opcodes); rounding differs from the two-branch form by ~2e-7 of W(0).
-                                    const float tq = fminf(fmaxf(1.0f - qn, 0.0f), 1.0f);                // one v_fma ... clamp
-                                    const float uq = fminf(fmaxf(0.5f - qn, 0.0f), 1.0f);
-                                    const float w = v_kw2 * (tq * tq * tq) - v_kw8 * (uq * uq * uq);
-                                    t.s0 += mVj * w;
-                                }
-                            }
+                            emit_micro(mask, tagbase, (unsigned)base << 4);
                         } else
                         while (mask) {  // rows coalesce across the wave's lanes (consecutive gi)
                             const unsigned bit = (unsigned)__ffs((int)mask) - 1u;
@@ -965,7 +1015,6 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                             }
                         }
                     }
-#undef SPH_ACC
                 }
             }
             // list overflow (extreme compression): the list-reading sweep must take the exact slow path; this
@@ -1212,7 +1261,7 @@ static int launch_brick(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, in
     int var = c->opt_variant;
     if ((unsigned long long)c->cap * 2ull * SPH_GLIST_ROWS >= (1ull << 32)) var &= SPH_VAR_PAD;
     if constexpr (MODE == GM_DENSITY_EOS) {
-        switch (var & 7) {
+        switch ((var & SPH_VAR_MIRROR) && (var & 7) == 5 ? 0 : (var & 7)) {
             case 1: return launch_brick_cfg<MODE, Cfg0, 1>(c, lo, hi, lo2, hi2);
             case 2: return launch_brick_cfg<MODE, Cfg0, 2>(c, lo, hi, lo2, hi2);
             case 3: return launch_brick_cfg<MODE, Cfg0, 3>(c, lo, hi, lo2, hi2);
@@ -1222,6 +1271,7 @@ static int launch_brick(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, in
             case 7: return launch_brick_cfg<MODE, Cfg0, 7>(c, lo, hi, lo2, hi2);
             default: break;
         }
+        if ((var & (SPH_VAR_MIRROR | 7)) == (SPH_VAR_MIRROR | 5)) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_MIRROR | 5>(c, lo, hi, lo2, hi2);
     }
     if constexpr (MODE == GM_FORCE_FUSED_U) {
         switch (var & (SPH_VAR_FORCE_BF | SPH_VAR_DEEP)) {

@@ -114,12 +114,14 @@ def analyse(x, h, label, BX=4, BY=2, BZ=4, margin=1.0002, sort_cells=False):
                     res["paired"] = res.get("paired", 0) + int(sum((H[:, a] + H[:, 8 - a]).max() for a in range(4)) + H[:, 4].max())
                     res["ideal"] += float(H.sum(1).mean())
                     res["filt_nat"] += int((((rlen[ids] + 7) // 8) * 8).max(0).sum())
+                    res["filt_sorted"] = res.get("filt_sorted", 0) + int((((-np.sort(-rlen[ids], axis=1) + 7) // 8) * 8).max(0).sum())
+                    res["filt_own"] = res.get("filt_own", 0) + float((((rlen[ids] + 7) // 8) * 8).sum(1).mean())
                     res["waves"] += 1
     w = max(res["waves"], 1)
     print(f"{label}: {N} particles, mean cell occupancy {cnt[cnt > 0].mean():.2f} (max {cnt.max()}), {w} interior waves")
     print(f"   mean hits per lane {res['ideal'] / w:.1f};  emission trips per wave: per 32-candidate chunk (the kernel) {res.get('chunked', 0) / w:.1f}, per run {res['natural'] / w:.1f}, "
           f"mirrored {res['mirrored'] / w:.1f}, antipodal pairs {res.get('paired', 0) / w:.1f}, sorted {res['sorted'] / w:.1f}, merged {res['merged'] / w:.1f};  "
-          f"filter candidates per wave (lock-step, 8 per trip) {res['filt_nat'] / w:.0f}")
+          f"filter candidates per wave (lock-step, 8 per trip) {res['filt_nat'] / w:.0f}, runs walked longest first {res.get('filt_sorted', 0) / w:.0f}, a lane's own {res.get('filt_own', 0) / w:.0f}")
     return res
 
 

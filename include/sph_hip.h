@@ -137,6 +137,8 @@ enum SphOption {
 #define SPH_VAR_FORCE_BF 8 /* force sweep: branch-free fluid pair term, buffer addressing for list and gather */
 #define SPH_VAR_DEEP 16    /* list-reading sweeps: list entries loaded a whole round (3 pairs) before they are decoded */
 #define SPH_VAR_MIRROR 32  /* density (with PAD | MICRO): all nine runs filtered first, hits emitted near side first */
+#define SPH_VAR_SORTED 64  /* with MIRROR: every lane emits its runs in order of descending hit count instead */
+#define SPH_VAR_GROUPS 128 /* with MIRROR: centre run, then the edge runs and the corner runs each by descending hit count */
 
 /* ms accumulated by sph_step since the last sph_reset_timings (HIP events on
  * the context's stream).  sort = K1+K2+K3 (initialize_particle_system),

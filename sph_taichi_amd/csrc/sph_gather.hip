@@ -694,6 +694,8 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
     constexpr bool V_2P = (VAR & SPH_VAR_2PHASE) != 0 && mode_inline_physics<MODE>();
     constexpr bool V_MICRO = (VAR & SPH_VAR_MICRO) != 0;
     constexpr bool V_MIRROR = (VAR & SPH_VAR_MIRROR) != 0 && V_PAD && V_MICRO;
+    constexpr bool V_SORTED = (VAR & (SPH_VAR_SORTED | SPH_VAR_GROUPS)) != 0 && V_MIRROR;
+    constexpr bool V_GROUPS = (VAR & SPH_VAR_GROUPS) != 0 && V_MIRROR;
     constexpr bool V_BF = (VAR & SPH_VAR_FORCE_BF) != 0 && MODE == GM_FORCE_FUSED_U;
     constexpr bool V_DEEP = (VAR & SPH_VAR_DEEP) != 0 && mode_reads_list<MODE>();
     constexpr bool INLINE_PHYS = mode_inline_physics<MODE>() && !V_2P;  // pair terms inside the emission loop
@@ -960,6 +962,38 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                     for (int base = lo + 32; base < hi; base += 32)
                         emit_micro(filter_chunk(base, min(32, hi - base)), ((unsigned)ncol << 11) | (unsigned)base, (unsigned)base << 4);
                 }
+                if (V_SORTED) {
+                    // SPH_VAR_SORTED: every lane emits its runs in order of descending hit count (a 25-exchange sorting
+                    // network on the nine words (hits << 16 | tag|base), the mask travels with its word): phase p then
+                    // costs the wave the p-th largest count of its busiest lane -- the bound for any per-lane order
+                    // (tools/emission_model.py: 64 -> 51 trips at rest, 81 -> 65 settled).
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) tk[r] |= (unsigned)__popc(mk[r]) << 16;
+#define SPH_CE(A_, B_) { const bool sw_ = tk[A_] < tk[B_]; const unsigned ta_ = tk[A_], ma_ = mk[A_]; \
+                         tk[A_] = sw_ ? tk[B_] : ta_; mk[A_] = sw_ ? mk[B_] : ma_; tk[B_] = sw_ ? ta_ : tk[B_]; mk[B_] = sw_ ? ma_ : mk[B_]; }
+                    if (V_GROUPS) {
+                        // SPH_VAR_GROUPS: the centre run first (it always holds the most hits), then the four edge runs and
+                        // the four corner runs each in descending order: ten exchanges instead of twenty-five
+                        SPH_CE(1, 3) SPH_CE(5, 7) SPH_CE(1, 5) SPH_CE(3, 7) SPH_CE(3, 5)
+                        SPH_CE(0, 2) SPH_CE(6, 8) SPH_CE(0, 6) SPH_CE(2, 8) SPH_CE(2, 6)
+                    } else {
+                    SPH_CE(0, 3) SPH_CE(1, 7) SPH_CE(2, 5) SPH_CE(4, 8)
+                    SPH_CE(0, 7) SPH_CE(2, 4) SPH_CE(3, 8) SPH_CE(5, 6)
+                    SPH_CE(0, 2) SPH_CE(1, 3) SPH_CE(4, 5) SPH_CE(7, 8)
+                    SPH_CE(1, 4) SPH_CE(3, 6) SPH_CE(5, 7)
+                    SPH_CE(0, 1) SPH_CE(2, 4) SPH_CE(3, 5) SPH_CE(6, 8)
+                    SPH_CE(2, 3) SPH_CE(4, 5) SPH_CE(6, 7)
+                    SPH_CE(1, 2) SPH_CE(3, 4) SPH_CE(5, 6)
+                    }
+#undef SPH_CE
+                    if (V_GROUPS) {
+                        constexpr int order[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
+#pragma unroll
+                        for (int p = 0; p < 9; ++p) emit_micro(mk[order[p]], tk[order[p]] & 0xffffu, (tk[order[p]] & 2047u) << 4);
+                    } else
+#pragma unroll
+                    for (int p = 0; p < 9; ++p) emit_micro(mk[p], tk[p] & 0xffffu, (tk[p] & 2047u) << 4);
+                } else {
                 const float half = 0.5f * d.grid_size;
                 const bool sxh = txl_ - (float)(ix - sx0) * d.grid_size >= half, syh = tyl_ - (float)(iy - sy0) * d.grid_size >= half;
 #pragma unroll
@@ -969,6 +1003,7 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                     const unsigned m_ = syh ? (sxh ? mk[rd] : mk[rc]) : (sxh ? mk[rb] : mk[ra]);
                     const unsigned t_ = syh ? (sxh ? tk[rd] : tk[rc]) : (sxh ? tk[rb] : tk[ra]);
                     emit_micro(m_, t_, (t_ & 2047u) << 4);
+                }
                 }
             } else
             // phase 1: filter the 9 column runs into the private index list (4 LDS slots in flight)
@@ -1271,7 +1306,11 @@ static int launch_brick(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, in
             case 7: return launch_brick_cfg<MODE, Cfg0, 7>(c, lo, hi, lo2, hi2);
             default: break;
         }
-        if ((var & (SPH_VAR_MIRROR | 7)) == (SPH_VAR_MIRROR | 5)) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_MIRROR | 5>(c, lo, hi, lo2, hi2);
+        if ((var & (SPH_VAR_MIRROR | 7)) == (SPH_VAR_MIRROR | 5)) {
+            if (var & SPH_VAR_GROUPS) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS | SPH_VAR_MIRROR | 5>(c, lo, hi, lo2, hi2);
+            if (var & SPH_VAR_SORTED) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_SORTED | SPH_VAR_MIRROR | 5>(c, lo, hi, lo2, hi2);
+            return launch_brick_cfg<MODE, Cfg0, SPH_VAR_MIRROR | 5>(c, lo, hi, lo2, hi2);
+        }
     }
     if constexpr (MODE == GM_FORCE_FUSED_U) {
         switch (var & (SPH_VAR_FORCE_BF | SPH_VAR_DEEP)) {

@@ -109,6 +109,15 @@ def analyse(x, h, label, BX=4, BY=2, BZ=4, margin=1.0002, sort_cells=False):
                         M[:, p] = H[np.arange(64), rx * 3 + ry]
                     res["mirrored"] += int(M.max(0).sum())
                     res["sorted"] += int((-np.sort(-H, axis=1)).max(0).sum())
+                    # centre run first, then the four edge runs and the four corner runs each by descending count
+                    gs = np.concatenate([H[:, [4]], -np.sort(-H[:, [1, 3, 5, 7]], axis=1), -np.sort(-H[:, [0, 2, 6, 8]], axis=1)], axis=1)
+                    res["group_sorted"] = res.get("group_sorted", 0) + int(gs.max(0).sum())
+                    Hc = hits_c[ids][:, :, 0]      # first 32-candidate chunk only (what the kernel keeps in registers)
+                    over = int(hits_c[ids][:, :, 1:].max(0).sum())
+                    res["k_mirror"] = res.get("k_mirror", 0) + over + int(np.stack([Hc[np.arange(64), np.where(sx[ids], 2 - p // 3, p // 3) * 3 + np.where(sy[ids], 2 - p % 3, p % 3)] for p in range(9)], 1).max(0).sum())
+                    res["k_sorted"] = res.get("k_sorted", 0) + over + int((-np.sort(-Hc, axis=1)).max(0).sum())
+                    gk = np.concatenate([Hc[:, [4]], -np.sort(-Hc[:, [1, 3, 5, 7]], axis=1), -np.sort(-Hc[:, [0, 2, 6, 8]], axis=1)], axis=1)
+                    res["k_group"] = res.get("k_group", 0) + over + int(gk.max(0).sum())
                     res["merged"] += int(H.sum(1).max())
                     # antipodal pairs emitted jointly: (dx,dy) with (-dx,-dy), centre alone
                     res["paired"] = res.get("paired", 0) + int(sum((H[:, a] + H[:, 8 - a]).max() for a in range(4)) + H[:, 4].max())
@@ -120,8 +129,9 @@ def analyse(x, h, label, BX=4, BY=2, BZ=4, margin=1.0002, sort_cells=False):
     w = max(res["waves"], 1)
     print(f"{label}: {N} particles, mean cell occupancy {cnt[cnt > 0].mean():.2f} (max {cnt.max()}), {w} interior waves")
     print(f"   mean hits per lane {res['ideal'] / w:.1f};  emission trips per wave: per 32-candidate chunk (the kernel) {res.get('chunked', 0) / w:.1f}, per run {res['natural'] / w:.1f}, "
-          f"mirrored {res['mirrored'] / w:.1f}, antipodal pairs {res.get('paired', 0) / w:.1f}, sorted {res['sorted'] / w:.1f}, merged {res['merged'] / w:.1f};  "
+          f"mirrored {res['mirrored'] / w:.1f}, centre + sorted edges + sorted corners {res.get('group_sorted', 0) / w:.1f}, antipodal pairs {res.get('paired', 0) / w:.1f}, sorted {res['sorted'] / w:.1f}, merged {res['merged'] / w:.1f};  "
           f"filter candidates per wave (lock-step, 8 per trip) {res['filt_nat'] / w:.0f}, runs walked longest first {res.get('filt_sorted', 0) / w:.0f}, a lane's own {res.get('filt_own', 0) / w:.0f}")
+    print(f"   as built (first chunk in registers, further chunks at once): mirrored {res.get('k_mirror', 0) / w:.1f}, sorted {res.get('k_sorted', 0) / w:.1f}, centre + sorted edges + sorted corners {res.get('k_group', 0) / w:.1f}")
     return res
 
 

@@ -14,12 +14,22 @@ N = 1 it is exactly the job's steps/s; at N > 1 (x-slab sharding, every rank own
 one 1.75 M slab: weak scaling) it is the whole-job aggregate.
 
 The JSON line also carries
-  roofline     : the dominant kernel (fused force sweep) -- algorithmic bytes per
-                 launch (60*N + 4*G) / its mean launch time from HIP
-                 events on the kernel's own stream, against the 8 TB/s HBM peak;
-  cpu_baseline : the CPU oracle (oracle/sph_oracle.c, "port" of the reference
-                 algorithm with OpenMP) timed on this box's host cores on a
-                 bounded sample of the same workload.
+  roofline      : the dominant kernel (the density + EOS sweep) -- algorithmic bytes per
+                  launch (32*N + 4*G) / its mean launch time from HIP events
+                  on the kernel's own stream, against the 8 TB/s HBM peak; `traffic`
+                  (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE) and the VALU figures come from
+                  profiles/pmc_traffic.json and are quoted only if that file was
+                  measured on the same kernel sources (fingerprint), else null;
+  roofline_valu : wave-level VALU instructions per launch / launch time against
+                  1024 SIMD-32 x 2.4 GHz / 2 cycles, and the useful FLOP rate of
+                  SURVEY 8d against 157.3 TFLOP/s (DESIGN.md section 4.4);
+  cpu_baseline  : the CPU oracle (oracle/sph_oracle.c, "port" of the reference
+                  algorithm with OpenMP; timing build -O3 -march=native) on the CPUs
+                  this container may use (cgroup quota), median of three bounded
+                  samples of the same workload;
+  neighbourhood : list lengths / cell occupancy of the last density sweep.
+--settle K times a developed flow, --variant M an A/B kernel instance, --ablate the
+section table of DESIGN.md section 4.4 (stderr).
 """
 from __future__ import annotations
 

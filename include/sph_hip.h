@@ -109,7 +109,9 @@ enum SphOption {
     SPH_OPT_GATHER_IMPL = 0,
     SPH_OPT_TIMING = 1,        /* 1 = record per-phase HIP events inside sph_step */
     SPH_OPT_FUSED_STEP = 2,    /* 1 (default) = sph_step uses the fused density+EOS / force kernels */
-    SPH_OPT_BRICK_SHAPE = 3,   /* index into the compiled brick-shape table */
+    SPH_OPT_BRICK_SHAPE = 3,   /* how the LDS-brick sweeps cut the grid: 0 (default) = 4 x 2 cell columns times a height chosen
+                                  per brick from the cell histogram (at most 4 layers, at most 256 targets, shell within the
+                                  LDS tile); 1 = fixed 4 x 2 x 4 bricks (the partition of ABI <= 2 builds, kept for A/B) */
     SPH_OPT_NO_DYNAMIC_SOLIDS = 4 /* 1 = the caller guarantees no dynamic solid particle exists (slab ranks
                                   cannot know this locally); skips the per-step device count */,
     SPH_OPT_DEBUG_ABLATE = 5,  /* profiling only: bit mask of sweep sections to skip (results are then wrong) */
@@ -139,6 +141,7 @@ enum SphOption {
 #define SPH_VAR_MIRROR 32  /* density (with PAD | MICRO): all nine runs filtered first, hits emitted near side first */
 #define SPH_VAR_SORTED 64  /* with MIRROR: every lane emits its runs in order of descending hit count instead */
 #define SPH_VAR_GROUPS 128 /* with MIRROR: centre run, then the edge runs and the corner runs each by descending hit count */
+#define SPH_VAR_RING 256   /* density (with PAD | MICRO): hit masks to a per-lane LDS ring, ONE balanced emission loop per lane */
 
 /* ms accumulated by sph_step since the last sph_reset_timings (HIP events on
  * the context's stream).  sort = K1+K2+K3 (initialize_particle_system),

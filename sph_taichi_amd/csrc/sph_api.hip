@@ -152,11 +152,11 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     rc = rc ? rc : alloc_dev(c, (void**)&c->scan_sums, (size_t)(c->scan_blocks + 1) * 4);
     rc = rc ? rc : alloc_dev(c, (void**)&c->glist, cap * 2 * SPH_GLIST_ROWS);
     rc = rc ? rc : alloc_dev(c, (void**)&c->gcnt, cap);
-    // smallest compiled brick is 2x2x4 cells
-    c->brick_cap = ((params->grid_num[0] + 1) / 2) * ((params->grid_num[1] + 1) / 2) * ((params->grid_num[2] + 3) / 4) + 8;
-    rc = rc ? rc : alloc_dev(c, (void**)&c->brick_list, (size_t)c->brick_cap * 4);
+    // bricks have a 4x2-column footprint and a height the list builder chooses (k_brick_list): at worst one per z layer
+    c->brick_cap = ((params->grid_num[0] + 3) / 4) * ((params->grid_num[1] + 1) / 2) * params->grid_num[2] + 8;
+    rc = rc ? rc : alloc_dev(c, (void**)&c->brick_list, (size_t)c->brick_cap * 8);
     rc = rc ? rc : alloc_dev(c, (void**)&c->brick_count, 16);
-    rc = rc ? rc : alloc_dev(c, (void**)&c->brick_list2, (size_t)c->brick_cap * 4);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->brick_list2, (size_t)c->brick_cap * 8);
     rc = rc ? rc : alloc_dev(c, (void**)&c->brick_count2, 16);
     const size_t cold = params->cold_capacity > 0 ? (size_t)params->cold_capacity : cap;
     if (cold < cap) { sph_destroy(c); return sph_fail(nullptr, SPH_E_INVALID, "sph_create: cold_capacity < capacity"); }
@@ -193,7 +193,7 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     sph_invalidate_lists(c);
     c->opt_uniform = -1; c->uniform_state = -1; c->m_uniform = 0.0f;  // SPH_OPT_UNIFORM_FLUID: auto
     c->opt_variant = SPH_VAR_DEFAULT;
-    if (const char* e = getenv("SPH_KERNEL_VARIANT")) c->opt_variant = atoi(e) & 255;  // A/B aid: the default mask of every context of this process
+    if (const char* e = getenv("SPH_KERNEL_VARIANT")) c->opt_variant = atoi(e) & 511;  // A/B aid: the default mask of every context of this process
     memset(&c->df_stats, 0, sizeof(c->df_stats));
     c->df.enable_divergence_solver = 1; c->df.m_max_iterations_v = 100; c->df.m_max_iterations = 100;  // DFSPH.py:12-20
     c->df.fluid_particle_num = 0; c->df.m_eps = 1e-5f; c->df.reserved_ = 0.0f; c->df.max_error_V = 0.1; c->df.max_error = 0.05;
@@ -228,13 +228,13 @@ int32_t sph_set_option(SphContext* c, int32_t option, int32_t value) {
         case SPH_OPT_GATHER_IMPL: if (value < 0 || value > 1) return sph_fail(c, SPH_E_INVALID, "gather impl must be 0 or 1"); c->opt_gather_impl = value; c->uniform_state = -1; return 0;
         case SPH_OPT_TIMING: c->opt_timing = value ? 1 : 0; return 0;
         case SPH_OPT_FUSED_STEP: c->opt_fused = value ? 1 : 0; return 0;
-        case SPH_OPT_BRICK_SHAPE: if (value < 0 || value > 3) return sph_fail(c, SPH_E_INVALID, "brick shape must be 0..3"); c->opt_brick_shape = value; return 0;
+        case SPH_OPT_BRICK_SHAPE: if (value < 0 || value > 1) return sph_fail(c, SPH_E_INVALID, "brick shape must be 0 (adaptive height) or 1 (fixed 4x2x4)"); c->opt_brick_shape = value; sph_invalidate_lists(c); return 0;
         case SPH_OPT_NO_DYNAMIC_SOLIDS: c->opt_no_dynamic = value ? 1 : 0; c->n_dyn_host = -1; c->uniform_state = -1; return 0;
         case SPH_OPT_DEBUG_ABLATE: c->opt_ablate = value; return 0;
         case SPH_OPT_SLAB_DROP_OUTSIDE: c->opt_drop_outside = value ? 1 : 0; c->uniform_state = -1; return 0;
         case SPH_OPT_SORT_BY_PID: c->opt_sort_by_pid = value ? 1 : 0; return 0;
         case SPH_OPT_KERNEL_VARIANT:
-            if (value < -1 || value > 255) return sph_fail(c, SPH_E_INVALID, "kernel variant must be -1 (default) or a mask of SPH_VAR_*");
+            if (value < -1 || value > 511) return sph_fail(c, SPH_E_INVALID, "kernel variant must be -1 (default) or a mask of SPH_VAR_*");
             c->opt_variant = value < 0 ? SPH_VAR_DEFAULT : value;
             sph_invalidate_lists(c);
             return 0;

@@ -599,6 +599,12 @@ __global__ __launch_bounds__(TPB) void k_gather_bvol_split(DevView d, const int*
 // In the fused step the density sweep writes each target's list to HBM
 // (glist[k*cap + i], gcnt[i]) and the force sweep -- same positions, same
 // brick layout -- reads it back instead of filtering again.
+// The buffer-addressed variants keep byte offsets (row * cap + i) * 2 in 32 bits.  The emission loop advances its
+// offset once per hit with a SATURATING add (a target can have as many hits as the tile has records; rows >= LISTCAP
+// are dropped by the buffer's range check, and an offset stuck at 2^32 - 1 stays out of range); the list readers form
+// the offsets of up to 8 rows past a list's end before clamping them.
+#define SPH_VOFF_ROWS (SPH_GLIST_ROWS + 8)
+#define SPH_BRICK_MAX_NZ 1000  // k_brick_list keeps four per-layer arrays per column group in LDS; taller grids take the cell walk
 #define SPH_CNT_WALK 255  // gcnt sentinel: this target must take the exact global cell walk (its brick's shell overflowed the LDS tile)
 #define SPH_CNT_LIST_OVF 254  // same consequence, other cause: the target's own list outgrew LISTCAP
 
@@ -612,10 +618,12 @@ __host__ __device__ constexpr bool mode_inline_physics() {
     return MODE == GM_DENSITY || MODE == GM_DENSITY_EOS || MODE == GM_DF_DENSITY;
 }
 
-template <int BX_, int BY_, int BZ_, int CAP_, int LISTCAP_>
+template <int BX_, int BY_, int BZ_, int CAP_, int LISTCAP_, int RD_ = 0>
 struct BrickCfg {
     static constexpr int BX = BX_, BY = BY_, BZ = BZ_, CAP = CAP_, LISTCAP = LISTCAP_;
+    static constexpr int RD = RD_;  // hit-mask ring slots per lane (SPH_VAR_RING; 0 = no ring)
     static constexpr int NCOL = (BX + 2) * (BY + 2);
+    static constexpr int NCELL = BX * BY * BZ;  // target cells of a brick
     static constexpr int NZS = BZ + 3;  // cell-end entries per column (start + BZ+2 ends)
     static constexpr int PER = (CAP + TPB - 1) / TPB;  // staged records per lane
     // LDS carve (bytes, every offset a multiple of 16).  Filtering sweeps stage float4 (-2x', -2y', -2z', |x'|^2)
@@ -628,48 +636,124 @@ struct BrickCfg {
     static constexpr int off_cols(bool has_w) { return off_colg(has_w) + 64 * 4; }
     static constexpr int off_tg(bool has_w) { return off_cols(has_w) + 80 * 4; }
     static constexpr int off_toff(bool has_w) { return off_tg(has_w) + 64 * 4; }
-    static constexpr int bytes(bool has_w) { return off_toff(has_w) + 80 * 4; }
+    static constexpr int off_tag(bool has_w) { return off_toff(has_w) + 80 * 4; }  // [NCELL][16] u16: tag|base of the cell's chunk k
+    static constexpr int off_ring(bool has_w) { return off_tag(has_w) + (RD > 0 ? NCELL * 16 * 2 : 0); }  // [RD][TPB] u32 hit masks
+    static constexpr int bytes(bool has_w) { return off_ring(has_w) + RD * TPB * 4; }
     static_assert(NCOL <= 32, "column id must fit 5 bits of a list entry");
     static_assert(CAP <= 2048, "LDS slot must fit 11 bits of a list entry");
+    static_assert(CAP % 4 == 0, "the m_V array starts on a 16-byte boundary");
+    static_assert(RD <= 16 && NCELL <= 64, "ring bookkeeping: 4-bit chunk ids in two registers; one lane of wave 1 per cell");
     static_assert(LISTCAP < SPH_CNT_LIST_OVF && LISTCAP <= SPH_GLIST_ROWS, "gcnt is a byte; glist has SPH_GLIST_ROWS rows");
     static_assert(bytes(true) <= 40960, "filtering sweeps: at least four workgroups per CU (160 KiB LDS)");
-    static_assert(bytes(false) <= 32768, "force sweep: five workgroups per CU");
+    static_assert(RD > 0 || bytes(false) <= 32768, "force sweep: five workgroups per CU (ring tiles belong to filtering sweeps only)");
 };
 
-// Non-empty bricks of one sweep: a brick is listed iff it holds at least one particle of a target layer.  The
-// gather kernel is persistent and walks this list, so (1) empty regions of the domain cost nothing and (2) the
-// per-XCD chunks are chunks of WORK: a fluid that fills a corner of the tank still loads all 8 XCDs evenly.
+// The bricks of one sweep.  A brick is a BX x BY footprint of (x, y) cell columns times a run of z layers whose HEIGHT
+// this kernel chooses, column group by column group, from the cell histogram: as many layers (<= BZ) as keep the
+// brick's targets within one round of the gather workgroup (tmax = 256 lanes) and its shell within the LDS tile
+// (smax records).  A resting lattice (8 particles per cell) gives 4-layer bricks of 256 targets; once the fluid has
+// settled to its rest density (10 per cell: the lattice of the scene files is 20 % under-dense, m_V0 = 0.8 d^3) a fixed
+// 4-layer brick would hold 320 targets -- a second round with one wave in four busy while the tile stays allocated --
+// and the cut moves to 3 layers of 240.  Empty layers are skipped; a brick is listed iff it holds a target.
+// fixed_bz > 0 = the fixed partition of rounds 1-2 (bricks aligned to multiples of fixed_bz layers), kept as the A/B
+// baseline (SPH_OPT_BRICK_SHAPE 1).
+// One wave per column group: lane z counts layer z's targets and shell records (cell_end differences), a wave64 scan
+// gives the prefixes, lane 0 walks them greedily; a workgroup (four column groups) takes ONE returning atomic per list.
+// Two lists in one array: bricks with many targets from the front (count[0]), light ones -- the partly filled
+// bricks along the fluid's surface and the tank walls -- from the back (count[1]).  The gather kernel starts
+// the heavy ones first, so that the launch drains on short jobs instead of on whatever came last.
 template <class CFG>
-__global__ __launch_bounds__(TPB) void k_brick_list(DevView d, int nbx, int nby, int nbz, int* __restrict__ list,
-                                                    int* __restrict__ count, int list_cap) {
-    // Two lists in one array: bricks with many targets from the front (count[0]), light ones -- the partly filled
-    // bricks along the fluid's surface and the tank walls -- from the back (count[1]).  The gather kernel starts
-    // the heavy ones first, so that the launch drains on short jobs instead of on whatever came last.
-    const int b = blockIdx.x * TPB + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    int tgt = 0;
-    if (b < nbx * nby * nbz) {
-        const int bzi = b % nbz, byi = (b / nbz) % nby, bxi = b / (nbz * nby);
-        const int cx0 = bxi * CFG::BX, cy0 = byi * CFG::BY, cz0 = bzi * CFG::BZ;
-        const int cx1 = min(cx0 + CFG::BX, d.nx), cy1 = min(cy0 + CFG::BY, d.ny), cz1 = min(cz0 + CFG::BZ, d.nz);
-        for (int ix = cx0; ix < cx1; ++ix) {
-            if (!((ix >= d.tgt_lo && ix < d.tgt_hi) || (ix >= d.tgt_lo2 && ix < d.tgt_hi2))) continue;
-            for (int iy = cy0; iy < cy1; ++iy) {
-                const int lo = sph_flatten(d, ix, iy, cz0), hi = sph_flatten(d, ix, iy, cz1 - 1);
-                tgt += d.cell_end[hi] - (lo > 0 ? d.cell_end[lo - 1] : 0);
+__global__ __launch_bounds__(TPB) void k_brick_list(DevView d, int nbx, int nby, int2* __restrict__ list,
+                                                    int* __restrict__ count, int list_cap, int tmax, int smax, int fixed_bz) {
+    extern __shared__ int sm_bl[];
+    __shared__ int s_cnt[TPB / 64][2];
+    __shared__ int s_base[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nz = d.nz;
+    int* Sp = sm_bl + wave * 4 * (nz + 1);  // [nz + 1] shell records in layers [0, z) of the column group's shell columns
+    int* Tp = Sp + (nz + 1);                // [nz + 1] targets in layers [0, z)
+    int* bz = Tp + (nz + 1);                // bricks of this column group: first layer | height << 16
+    int* bt = bz + (nz + 1);                //                              targets
+    const int cg = blockIdx.x * (TPB / 64) + wave;
+    const bool live = cg < nbx * nby;
+    const int bxi = cg / nby, byi = cg % nby;
+    const int cx0 = bxi * CFG::BX, cy0 = byi * CFG::BY;
+    const int cx1 = min(cx0 + CFG::BX, d.nx), cy1 = min(cy0 + CFG::BY, d.ny);  // excl.
+    const int sx0 = max(cx0 - 1, 0), sy0 = max(cy0 - 1, 0);
+    const int sx1 = min(cx1, d.nx - 1), sy1 = min(cy1, d.ny - 1);  // incl.
+    int carryS = 0, carryT = 0;
+    if (live && lane == 0) { Sp[0] = 0; Tp[0] = 0; }
+    for (int zb = 0; zb < nz; zb += 64) {
+        const int z = zb + lane;
+        int s_ = 0, t_ = 0;
+        if (live && z < nz) {
+            for (int ix = sx0; ix <= sx1; ++ix) {
+                const bool tx = ix >= cx0 && ix < cx1 &&
+                                ((ix >= d.tgt_lo && ix < d.tgt_hi) || (ix >= d.tgt_lo2 && ix < d.tgt_hi2));
+                for (int iy = sy0; iy <= sy1; ++iy) {
+                    const int f = sph_flatten(d, ix, iy, z);
+                    const int n = d.cell_end[f] - (f > 0 ? d.cell_end[f - 1] : 0);
+                    s_ += n;
+                    if (tx && iy >= cy0 && iy < cy1) t_ += n;
+                }
             }
         }
+        const int si = sph_wave_inclusive_scan(s_, lane), ti = sph_wave_inclusive_scan(t_, lane);
+        if (live && z < nz) { Sp[z + 1] = carryS + si; Tp[z + 1] = carryT + ti; }
+        carryS += __shfl(si, 63, 64);
+        carryT += __shfl(ti, 63, 64);
     }
-    const bool heavy = tgt >= SPH_BRICK_HEAVY, light = tgt > 0 && !heavy;
-    const unsigned long long mh = __ballot(heavy), ml = __ballot(light);
-    int baseh = 0, basel = 0;
-    if (lane == 0 && mh) baseh = atomicAdd(&count[0], __popcll(mh));
-    if (lane == 0 && ml) basel = atomicAdd(&count[1], __popcll(ml));
-    baseh = __shfl(baseh, 0, 64);
-    basel = __shfl(basel, 0, 64);
+    __syncthreads();
+    int nb = 0;
+    if (live && lane == 0) {
+        int z = 0;
+        while (z < nz) {
+            if (Tp[z + 1] == Tp[z]) { ++z; continue; }  // no target in this layer
+            int z1;
+            if (fixed_bz > 0) {
+                z = (z / fixed_bz) * fixed_bz;
+                z1 = min(z + fixed_bz, nz);
+            } else {
+                z1 = z + 1;
+                while (z1 < nz && z1 - z < CFG::BZ && Tp[z1 + 1] != Tp[z1]) {
+                    if (Tp[z1 + 1] - Tp[z] > tmax || Sp[min(z1 + 2, nz)] - Sp[max(z - 1, 0)] > smax) break;
+                    ++z1;
+                }
+            }
+            bz[nb] = z | ((z1 - z) << 16);
+            bt[nb] = Tp[z1] - Tp[z];
+            ++nb;
+            z = z1;
+        }
+    }
+    nb = __shfl(nb, 0, 64);
+    int nh = 0;
+    for (int k0 = 0; k0 < nb; k0 += 64) {
+        const int k = k0 + lane;
+        nh += __popcll(__ballot(k < nb && bt[k] >= SPH_BRICK_HEAVY));  // (lane 0's LDS writes: same wave, program order)
+    }
+    if (lane == 0) { s_cnt[wave][0] = nh; s_cnt[wave][1] = nb - nh; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int th = 0, tl = 0;
+        for (int w = 0; w < TPB / 64; ++w) { th += s_cnt[w][0]; tl += s_cnt[w][1]; }
+        s_base[0] = th ? atomicAdd(&count[0], th) : 0;
+        s_base[1] = tl ? atomicAdd(&count[1], tl) : 0;
+    }
+    __syncthreads();
+    int oh = s_base[0], ol = s_base[1];
+    for (int w = 0; w < wave; ++w) { oh += s_cnt[w][0]; ol += s_cnt[w][1]; }
     const unsigned long long below = (1ull << lane) - 1ull;
-    if (heavy) list[baseh + __popcll(mh & below)] = b;
-    if (light) list[list_cap - 1 - (basel + __popcll(ml & below))] = b;
+    for (int k0 = 0; k0 < nb; k0 += 64) {
+        const int k = k0 + lane;
+        const bool ok = k < nb;
+        const bool heavy = ok && bt[k] >= SPH_BRICK_HEAVY, light = ok && !heavy;
+        const unsigned long long mh = __ballot(heavy), ml = __ballot(light);
+        if (heavy) list[oh + __popcll(mh & below)] = make_int2(cg, bz[k]);
+        if (light) list[list_cap - 1 - (ol + __popcll(ml & below))] = make_int2(cg, bz[k]);
+        oh += __popcll(mh);
+        ol += __popcll(ml);
+    }
 }
 
 // a uniform value held in a VGPR: on gfx950 a VALU instruction with an SGPR source issues at half rate
@@ -684,7 +768,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sph_rsrc(const void* p, unsign
 // second launch bound = waves per SIMD the LDS tile allows anyway (four workgroups per CU for the filtering sweeps, five
 // for the list-reading ones): the register allocator must not go past 128 / 96 VGPRs, or a resident slot is lost
 template <int MODE, class CFG, int VAR = 0>
-__global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gather_brick(DevView d, int nby, int nbz, const int* __restrict__ brick_list,
+__global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gather_brick(DevView d, int nby, const int2* __restrict__ brick_list,
                                                       const int* __restrict__ brick_count,
                                                       unsigned short* __restrict__ glist,
                                                       unsigned char* __restrict__ gcnt, int cap, int list_cap) {
@@ -693,7 +777,8 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
     constexpr bool V_PAD = (VAR & SPH_VAR_PAD) != 0;
     constexpr bool V_2P = (VAR & SPH_VAR_2PHASE) != 0 && mode_inline_physics<MODE>();
     constexpr bool V_MICRO = (VAR & SPH_VAR_MICRO) != 0;
-    constexpr bool V_MIRROR = (VAR & SPH_VAR_MIRROR) != 0 && V_PAD && V_MICRO;
+    constexpr bool V_RING = (VAR & SPH_VAR_RING) != 0 && V_PAD && V_MICRO && CFG::RD > 0 && mode_inline_physics<MODE>();
+    constexpr bool V_MIRROR = (VAR & SPH_VAR_MIRROR) != 0 && V_PAD && V_MICRO && !V_RING;
     constexpr bool V_SORTED = (VAR & (SPH_VAR_SORTED | SPH_VAR_GROUPS)) != 0 && V_MIRROR;
     constexpr bool V_GROUPS = (VAR & SPH_VAR_GROUPS) != 0 && V_MIRROR;
     constexpr bool V_BF = (VAR & SPH_VAR_FORCE_BF) != 0 && MODE == GM_FORCE_FUSED_U;
@@ -720,7 +805,7 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
     const int nbh = brick_count[0], nbl = brick_count[1];
     const int chunkh = (nbh + 7) >> 3, chunkl = (nbl + 7) >> 3;
     const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
-    int brick;
+    int2 brick;
     if (slot < chunkh) {  // heavy bricks first (blocks are dispatched in blockIdx order) ...
         const int kb = xcd * chunkh + slot;
         if (kb >= nbh) return;
@@ -731,11 +816,11 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
         brick = brick_list[list_cap - 1 - kb];
     }
     {
-    const int bzi = brick % nbz;
-    const int byi = (brick / nbz) % nby;
-    const int bxi = brick / (nbz * nby);
-    const int cx0 = bxi * CFG::BX, cy0 = byi * CFG::BY, cz0 = bzi * CFG::BZ;
-    const int cx1 = min(cx0 + CFG::BX, d.nx), cy1 = min(cy0 + CFG::BY, d.ny), cz1 = min(cz0 + CFG::BZ, d.nz);  // excl.
+    // (column group, first z layer | height << 16): the partition of k_brick_list
+    const int byi = brick.x % nby;
+    const int bxi = brick.x / nby;
+    const int cx0 = bxi * CFG::BX, cy0 = byi * CFG::BY, cz0 = brick.y & 0xffff;
+    const int cx1 = min(cx0 + CFG::BX, d.nx), cy1 = min(cy0 + CFG::BY, d.ny), cz1 = min(cz0 + (brick.y >> 16), d.nz);  // excl.
     const int sx0 = max(cx0 - 1, 0), sy0 = max(cy0 - 1, 0), sz0 = max(cz0 - 1, 0);
     const int sx1 = min(cx1, d.nx - 1), sy1 = min(cy1, d.ny - 1), sz1 = min(cz1, d.nz - 1);  // incl.
     const int ncy = sy1 - sy0 + 1;
@@ -802,6 +887,27 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
         Bi_0 = d.vf[gi_0];
         Ei_0 = target_load_E<MODE>(d, gi_0);
         key_0 = d.key[gi_0];
+    }
+
+    // SPH_VAR_RING: tag|base of every 32-candidate chunk of every target cell, in the order the filter walks them (nine
+    // column runs, a run in chunks of 32): one lane of wave 1 per cell.  A target finds its cell's row by
+    // (brick column, z layer); the emission loop looks a chunk up by its ordinal.
+    if (V_RING && !overflow && wave == 1 && lane < CFG::NCELL) {
+        const int colb = lane / CFG::BZ, zc = lane % CFG::BZ;
+        const int ix = cx0 + colb / CFG::BY, iy = cy0 + colb % CFG::BY, cz = cz0 + zc;
+        if (ix < cx1 && iy < cy1 && cz < cz1) {
+            const int klo = (cz > 0 ? cz - 1 : 0) - sz0, khi = (cz < d.nz - 1 ? cz + 1 : d.nz - 1) - sz0;
+            unsigned short* row = reinterpret_cast<unsigned short*>(smem + CFG::off_tag(HAS_W)) + lane * 16;
+            int kc = 0;
+            for (int r = 0; r < 9; ++r) {
+                const int nx = ix + r / 3 - 1, ny = iy + r % 3 - 1;
+                if (nx < 0 || nx >= d.nx || ny < 0 || ny >= d.ny) continue;
+                const int ncol = (nx - sx0) * ncy + (ny - sy0);
+                const int rel = -sColG[ncol];
+                const int lo = sCE[ncol * CFG::NZS + klo] + rel, hi = sCE[ncol * CFG::NZS + khi + 1] + rel;
+                for (int base = lo; base < hi && kc < 16; base += 32, ++kc) row[kc] = (unsigned short)(((unsigned)ncol << 11) | (unsigned)base);
+            }
+        }
     }
 
     // ---- step B: stage the shell's (x, y, z, m_V) records; all loads of a lane in flight together ----
@@ -906,6 +1012,24 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                 return mask;
             };
 #undef SPH_ACC
+            // density pair term of the hit whose record sits at LDS byte offset aq of the Q array (addresses and
+            // constants arranged for the issue rates)
+            auto pair_term = [&](unsigned aq) {
+                const float4 q4 = *reinterpret_cast<const float4*>(smem + CFG::OFF_Q + aq);
+                const float mVj = *reinterpret_cast<const float*>(smem + CFG::off_w(true) + (aq >> 2));
+                const float rx = fmaf(0.5f, q4.x, txl_), ry = fmaf(0.5f, q4.y, tyl_), rz = fmaf(0.5f, q4.z, tzl_);
+                const float r2 = rx * rx + ry * ry + rz * rz;
+                const float qn = r2 * __builtin_amdgcn_rsqf(r2 + 1e-30f) * v_inv_h;  // r2 = 0 (self): 0 * 1e15 = 0
+                // sph_base.py:23-44 in one expression for both branches: with t = (1-q)+ and
+                // u = (1/2-q)+ the cubic spline is k (2 t^3 - 8 u^3) -- for q <= 1/2 this IS
+                // k (6 q^3 - 6 q^2 + 1), beyond it u = 0 leaves the outer branch, from q = 1 on t = 0.
+                // Two clamped FMAs replace the compare + select and the second polynomial (all
+                // full-rate opcodes); rounding differs from the two-branch form by ~2e-7 of W(0).
+                const float tq = fminf(fmaxf(1.0f - qn, 0.0f), 1.0f);                // one v_fma ... clamp
+                const float uq = fminf(fmaxf(0.5f - qn, 0.0f), 1.0f);
+                const float w = v_kw2 * (tq * tq * tq) - v_kw8 * (uq * uq * uq);
+                t.s0 += mVj * w;
+            };
             // V_MICRO: the hits of one mask become list entries `tagbase + bit` and (inline sweeps) density terms
             auto emit_micro = [&](unsigned mask, unsigned tagbase, unsigned base16) {
                 cnt += __popc(mask);
@@ -913,26 +1037,78 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                     const unsigned bit = (unsigned)__ffs((int)mask) - 1u;
                     mask &= mask - 1u;
                     if (!(d.ablate & 2)) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(tagbase + bit), lrs, (int)voff, 0, 0);
-                    voff += vcap2;
-                    if (INLINE_PHYS && !(d.ablate & 32)) {  // the pair term of the legacy loop below, addresses and constants arranged for the issue rates
-                        const unsigned aq = base16 + (bit << 4);
-                        const float4 q4 = *reinterpret_cast<const float4*>(smem + CFG::OFF_Q + aq);
-                        const float mVj = *reinterpret_cast<const float*>(smem + CFG::off_w(true) + (aq >> 2));
-                        const float rx = fmaf(0.5f, q4.x, txl_), ry = fmaf(0.5f, q4.y, tyl_), rz = fmaf(0.5f, q4.z, tzl_);
-                        const float r2 = rx * rx + ry * ry + rz * rz;
-                        const float qn = r2 * __builtin_amdgcn_rsqf(r2 + 1e-30f) * v_inv_h;  // r2 = 0 (self): 0 * 1e15 = 0
-                        // sph_base.py:23-44 in one expression for both branches: with t = (1-q)+ and
-                        // u = (1/2-q)+ the cubic spline is k (2 t^3 - 8 u^3) -- for q <= 1/2 this IS
-                        // k (6 q^3 - 6 q^2 + 1), beyond it u = 0 leaves the outer branch, from q = 1 on t = 0.
-                        // Two clamped FMAs replace the compare + select and the second polynomial (all
-                        // full-rate opcodes); rounding differs from the two-branch form by ~2e-7 of W(0).
-                        const float tq = fminf(fmaxf(1.0f - qn, 0.0f), 1.0f);                // one v_fma ... clamp
-                        const float uq = fminf(fmaxf(0.5f - qn, 0.0f), 1.0f);
-                        const float w = v_kw2 * (tq * tq * tq) - v_kw8 * (uq * uq * uq);
-                        t.s0 += mVj * w;
-                    }
+                    voff = __builtin_elementwise_add_sat(voff, vcap2);
+                    if (INLINE_PHYS && !(d.ablate & 32)) pair_term(base16 + (bit << 4));
                 }
             };
+            if (V_RING) {
+                // SPH_VAR_RING: the non-empty hit masks go to a per-lane ring in LDS (slot s of lane t at
+                // ring[s * TPB + t]: conflict-free whatever s each lane is at), the ordinals of their chunks to two
+                // registers of 4-bit fields; then ONE loop per lane takes a hit per trip from whatever mask the lane is
+                // at, refilling from the ring (next mask and its tag|base are fetched a mask ahead).  LDS is per-lane
+                // indexable where registers are not: the loop runs as many trips as the wave's busiest lane has hits
+                // (33 on the rest lattice, ~52 settled) instead of the sum over the runs of the per-run maxima (68 / 69
+                // with the group-sorted emission), every lane is at list row `trip` in every trip -- the u16 row
+                // stores of a wave fall into ONE 128-byte line per trip instead of one line per diverged lane -- and
+                // no mask lives in a register across the filter.
+                unsigned* const ring = reinterpret_cast<unsigned*>(smem + CFG::off_ring(HAS_W)) + tid;
+                const unsigned short* const tagrow = reinterpret_cast<const unsigned short*>(smem + CFG::off_tag(HAS_W)) +
+                                                     (((ix - cx0) * CFG::BY + (iy - cy0)) * CFG::BZ + (cz - cz0)) * 16;
+                unsigned ids_lo = 0, ids_hi = 0;
+                int w = 0, kc = 0;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) {
+                    const int nx = ix + r / 3 - 1, ny = iy + r % 3 - 1;
+                    if (nx < 0 || nx >= d.nx || ny < 0 || ny >= d.ny) continue;
+                    const int ncol = (nx - sx0) * ncy + (ny - sy0);
+                    const int rel = -sColG[ncol];
+                    const int lo = sCE[ncol * CFG::NZS + klo] + rel, hi = sCE[ncol * CFG::NZS + khi + 1] + rel;
+                    for (int base = lo; base < hi; base += 32, ++kc) {
+                        const unsigned mask = filter_chunk(base, min(32, hi - base));
+                        if (mask == 0u) continue;
+                        if (kc < 16 && w < CFG::RD) {
+                            ring[w * TPB] = mask;
+                            const unsigned f = (unsigned)kc << ((unsigned)(w & 7) * 4u);
+                            if (w < 8) ids_lo |= f; else ids_hi |= f;
+                            ++w;
+                            cnt += __popc(mask);
+                        } else {  // a crowded neighbourhood (more than RD non-empty chunks): emitted on the spot
+                            emit_micro(mask, ((unsigned)ncol << 11) | (unsigned)base, (unsigned)base << 4);
+                        }
+                    }
+                }
+                // A trip that takes a mask's last hit requests the lane's next mask and its tag|base FIRST, so that they
+                // come back behind the pair term's own reads while that is being computed, and hands over at the bottom
+                // of the same trip.  The two reads and their wait are issued by hand: left to itself the compiler sinks
+                // the reads to their use (and waits there), and a `volatile` read becomes a flat load.  Nothing may touch
+                // m_ / tg_ between the reads and the wait (the compiler does not know they are in flight): they are
+                // defined and consumed inside one iteration, and tools/check_isa.py looks at the generated code.
+                const unsigned ring_a = (unsigned)(uintptr_t)(smem + CFG::off_ring(HAS_W)) + (unsigned)tid * 4u;
+                const unsigned tag_a = (unsigned)(uintptr_t)tagrow;
+                auto chunk_id = [&](int slot) -> unsigned { return ((slot < 8 ? ids_lo : ids_hi) >> ((unsigned)(slot & 7) * 4u)) & 15u; };
+                unsigned cur = w > 0 ? ring[0] : 0u, cb = tagrow[chunk_id(0)];
+                int taken = 1;  // masks taken so far = ring slot of the next one
+                while (cur != 0u) {
+                    const unsigned bit = (unsigned)__ffs((int)cur) - 1u;
+                    const unsigned rest = cur & (cur - 1u);
+                    unsigned m_ = 0u, tg_ = 0u;
+                    if (rest == 0u) {
+                        const int tk = min(taken, CFG::RD - 1);  // (always a valid slot; beyond the lane's last mask the value is dropped)
+                        asm volatile("ds_read_b32 %0, %2\n\tds_read_u16 %1, %3"
+                                     : "=&v"(m_), "=&v"(tg_) : "v"(ring_a + (unsigned)tk * (unsigned)(TPB * 4)), "v"(tag_a + (chunk_id(tk) << 1)));
+                    }
+                    if (!(d.ablate & 2)) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(cb + bit), lrs, (int)voff, 0, 0);
+                    voff = __builtin_elementwise_add_sat(voff, vcap2);
+                    if (!(d.ablate & 32)) pair_term((((cb & 2047u) + bit) << 4));
+                    cur = rest;
+                    if (rest == 0u) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(m_), "+v"(tg_));
+                        cur = taken < w ? m_ : 0u;
+                        cb = tg_;
+                        ++taken;
+                    }
+                }
+            } else
             if (V_MIRROR) {
                 // SPH_VAR_MIRROR: filter all nine runs first (their first 32 candidates: one mask and one tag|base per
                 // run stay in registers; longer runs emit their further chunks at once), then emit NEAR SIDE FIRST:
@@ -1218,10 +1394,10 @@ __global__ __launch_bounds__(TPB) void k_eos(DevView d) {
 // ---------------------------------------------------------------------------
 // host-side launchers
 // ---------------------------------------------------------------------------
-typedef BrickCfg<4, 2, 4, 1792, 95> Cfg0;  // 4x2x4 cells: 1152 candidates / 256 targets at rest
-typedef BrickCfg<2, 2, 8, 1792, 95> Cfg1;  // 2x2x8 cells: 1280 candidates / 256 targets at rest
-typedef BrickCfg<2, 4, 4, 1792, 95> Cfg2;  // 2x4x4 cells
-typedef BrickCfg<2, 2, 4, 1792, 95> Cfg3;  // 2x2x4 cells:  768 candidates / 128 targets at rest
+typedef BrickCfg<4, 2, 4, 1792, 95> Cfg0;  // 4x2 columns x up to 4 layers: 1152 candidates / 256 targets at rest
+typedef BrickCfg<4, 2, 4, 1392, 95, 10> CfgR;  // the same bricks with the hit-mask ring of SPH_VAR_RING beside a smaller tile (k_brick_list cuts for it)
+// shell records a brick may hold (the cut rule of k_brick_list): the smallest tile among the kernels of the step
+static int brick_smax(const SphContext* c) { return (c->opt_variant & SPH_VAR_RING) ? CfgR::CAP : Cfg0::CAP; }
 
 template <int MODE>
 static int launch_simple(SphContext* c, const int* list, int n) {
@@ -1243,9 +1419,9 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
     if (d.tgt_hi2 <= d.tgt_lo2) d.tgt_lo2 = d.tgt_hi2 = 0;
     if (d.tgt_hi <= d.tgt_lo) { d.tgt_lo = d.tgt_lo2; d.tgt_hi = d.tgt_hi2; d.tgt_lo2 = d.tgt_hi2 = 0; }
     if (d.tgt_hi <= d.tgt_lo) return 0;
-    const int nbx = (d.nx + CFG::BX - 1) / CFG::BX, nby = (d.ny + CFG::BY - 1) / CFG::BY,
-              nbz = (d.nz + CFG::BZ - 1) / CFG::BZ;
-    const int nbricks = nbx * nby * nbz;
+    const int nbx = (d.nx + CFG::BX - 1) / CFG::BX, nby = (d.ny + CFG::BY - 1) / CFG::BY;
+    const int ncg = nbx * nby;          // column groups
+    const int nbricks = ncg * d.nz;     // at worst every z layer is a brick of its own
     if (nbricks > c->brick_cap) return sph_fail(c, SPH_E_INVALID, "brick list capacity exceeded");
     const int bytes = CFG::bytes(!mode_reads_list<MODE>());
     static bool attr_set[64] = {};  // per device: the attribute belongs to the function ON a device
@@ -1256,11 +1432,14 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
         attr_set[dev] = true;
     }
     const int grid = (nbricks + 7) / 8 * 8 + 8;  // per XCD: ceil(heavy / 8) + ceil(light / 8) <= ceil(nbricks / 8) + 1 slots
-    // the list of non-empty bricks depends only on the order and the target layers: every sweep of a step that
-    // shares them (density + force; all ~30 sweeps of a DFSPH step) reuses it
-    const int key[5] = {CFG::BX * 100 + CFG::BY * 10 + CFG::BZ, d.tgt_lo, d.tgt_hi, d.tgt_lo2, d.tgt_hi2};
+    // The partition depends only on the order, the target layers and the cut rule: every sweep of a step that shares
+    // them (density + force; all ~30 sweeps of a DFSPH step) reuses it -- and MUST, where one sweep reads the lists
+    // another wrote (list entries are brick-relative).
+    const int fixed_bz = c->opt_brick_shape == 1 ? CFG::BZ : 0;
+    const int tmax = TPB, smax = brick_smax(c);
+    const int key[5] = {((CFG::BX * 10 + CFG::BY) * 10 + CFG::BZ) * 4096 + fixed_bz * 2048 + smax, d.tgt_lo, d.tgt_hi, d.tgt_lo2, d.tgt_hi2};
     hipStream_t st = sph_stream(c);
-    int* blist = c->use_side ? c->brick_list2 : c->brick_list;
+    int2* blist = c->use_side ? c->brick_list2 : c->brick_list;
     int* bcount = c->use_side ? c->brick_count2 : c->brick_count;
     // A cached list also serves a sweep whose single target range lies INSIDE the cached one (slab mode: the force
     // sweep over the owned layers after the density sweep over owned + first ghost layers): bricks listed for the wider
@@ -1270,14 +1449,15 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
     if (c->use_side || !c->bricks_valid || (memcmp(key, c->bricks_key, sizeof(key)) != 0 && !subset)) {
         if (c->use_side || !c->brick_count_zero) SPH_HIP(c, hipMemsetAsync(bcount, 0, 2 * sizeof(int), st));
         if (!c->use_side) c->brick_count_zero = false;
-        hipLaunchKernelGGL((k_brick_list<CFG>), dim3((nbricks + TPB - 1) / TPB), dim3(TPB), 0, st, d, nbx, nby, nbz, blist, bcount, c->brick_cap);
+        hipLaunchKernelGGL((k_brick_list<CFG>), dim3((ncg + TPB / 64 - 1) / (TPB / 64)), dim3(TPB), (size_t)(TPB / 64) * 4 * (d.nz + 1) * sizeof(int),
+                           st, d, nbx, nby, blist, bcount, c->brick_cap, tmax, smax, fixed_bz);
         SPH_LAUNCH_CHECK(c);
         if (!c->use_side) {  // (the side stream's list is private to that launch and never cached)
             memcpy(c->bricks_key, key, sizeof(key));
             c->bricks_valid = true;
         }
     }
-    hipLaunchKernelGGL((k_gather_brick<MODE, CFG, VAR>), dim3(grid), dim3(TPB), bytes, st, d, nby, nbz, blist, bcount, c->glist,
+    hipLaunchKernelGGL((k_gather_brick<MODE, CFG, VAR>), dim3(grid), dim3(TPB), bytes, st, d, nby, blist, bcount, c->glist,
                        c->gcnt, c->cap, c->brick_cap);
     SPH_LAUNCH_CHECK(c);
     return 0;
@@ -1285,17 +1465,12 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
 
 template <int MODE>
 static int launch_brick(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, int hi2 = 0) {
-    switch (c->opt_brick_shape) {
-        case 1: return launch_brick_cfg<MODE, Cfg1>(c, lo, hi, lo2, hi2);
-        case 2: return launch_brick_cfg<MODE, Cfg2>(c, lo, hi, lo2, hi2);
-        case 3: return launch_brick_cfg<MODE, Cfg3>(c, lo, hi, lo2, hi2);
-        default: break;
-    }
     // SPH_OPT_KERNEL_VARIANT: A/B instances of the two sweeps of the fused WCSPH step (default brick shape only).
-    // The buffer-addressed variants hold byte offsets in 32 bits: 64 list rows of 2 * cap bytes must fit.
+    // The buffer-addressed variants hold byte offsets in 32 bits (SPH_VOFF_ROWS).
     int var = c->opt_variant;
-    if ((unsigned long long)c->cap * 2ull * SPH_GLIST_ROWS >= (1ull << 32)) var &= SPH_VAR_PAD;
+    if ((unsigned long long)c->cap * 2ull * SPH_VOFF_ROWS >= (1ull << 32)) var &= SPH_VAR_PAD;
     if constexpr (MODE == GM_DENSITY_EOS) {
+        if ((var & SPH_VAR_RING) && (var & 7) == 5) return launch_brick_cfg<MODE, CfgR, SPH_VAR_RING | 5>(c, lo, hi, lo2, hi2);
         switch ((var & SPH_VAR_MIRROR) && (var & 7) == 5 ? 0 : (var & 7)) {
             case 1: return launch_brick_cfg<MODE, Cfg0, 1>(c, lo, hi, lo2, hi2);
             case 2: return launch_brick_cfg<MODE, Cfg0, 2>(c, lo, hi, lo2, hi2);
@@ -1329,7 +1504,7 @@ static int launch_brick(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, in
 // force sweep over the targets of x layers [lo, hi) only (slab mode: boundary layers first, interior later)
 int sphk_gather_layers(SphContext* c, int mode, int lo, int hi, int lo2, int hi2) {
     if (c->N <= 0 || (hi <= lo && hi2 <= lo2)) return 0;
-    if (mode != GM_FORCE_FUSED || c->opt_gather_impl == 0) return sph_fail(c, SPH_E_INVALID, "layer-restricted sweeps need the brick force kernel");
+    if (mode != GM_FORCE_FUSED || c->opt_gather_impl == 0 || c->p.grid_num[2] > SPH_BRICK_MAX_NZ) return sph_fail(c, SPH_E_INVALID, "layer-restricted sweeps need the brick force kernel");
     if (hi < lo) hi = lo;
     if (c->uniform_state == 1 && c->lists_valid && c->stg_kind == 1) return launch_brick<GM_FORCE_FUSED_U>(c, lo, hi, lo2, hi2);
     return launch_brick<GM_FORCE_FUSED>(c, lo, hi, lo2, hi2);
@@ -1338,7 +1513,7 @@ int sphk_gather_layers(SphContext* c, int mode, int lo, int hi, int lo2, int hi2
 template <int MODE>
 static int launch_sweep(SphContext* c) {
     if (c->N <= 0) return 0;
-    if (c->opt_gather_impl == 0) return launch_simple<MODE>(c, nullptr, c->N);
+    if (c->opt_gather_impl == 0 || c->p.grid_num[2] > SPH_BRICK_MAX_NZ) return launch_simple<MODE>(c, nullptr, c->N);
     int rc = launch_brick<MODE>(c);
     if (!rc && mode_writes_list<MODE>()) c->lists_valid = true;
     if (!rc && MODE == GM_DENSITY_EOS) c->stg_kind = c->uniform_state == 1 ? 1 : 0;
@@ -1351,7 +1526,7 @@ static int launch_sweep(SphContext* c) {
 template <int MODE>
 static int launch_df(SphContext* c) {
     if (c->N <= 0) return 0;
-    if (c->opt_gather_impl == 0 || (mode_reads_list<MODE>() && !c->lists_valid)) {
+    if (c->opt_gather_impl == 0 || c->p.grid_num[2] > SPH_BRICK_MAX_NZ || (mode_reads_list<MODE>() && !c->lists_valid)) {
         if (mode_is_df_vdiv<MODE>()) c->k_kind = 0;  // density_adv changes, the walk does not refresh k_j
         return launch_simple<MODE>(c, nullptr, c->N);
     }
@@ -1359,11 +1534,13 @@ static int launch_df(SphContext* c) {
     // offsets are 32-bit: see launch_brick).  The early entry loads of SPH_VAR_DEEP do nothing for these sweeps
     // (DFSPH step 3.46 vs 3.51 ms with them, profiles/r02g): their pair terms gather 4 bytes, not a 16-byte record.
     int var = c->opt_variant;
-    if ((unsigned long long)c->cap * 2ull * SPH_GLIST_ROWS >= (1ull << 32)) var &= SPH_VAR_PAD;
+    if ((unsigned long long)c->cap * 2ull * SPH_VOFF_ROWS >= (1ull << 32)) var &= SPH_VAR_PAD;
     int rc;
-    if (mode_writes_list<MODE>() && (var & (SPH_VAR_PAD | SPH_VAR_MICRO)) == (SPH_VAR_PAD | SPH_VAR_MICRO))
-        rc = launch_brick_cfg<MODE, Cfg0, mode_writes_list<MODE>() ? (SPH_VAR_PAD | SPH_VAR_MICRO) : 0>(c);
-    else
+    if constexpr (mode_writes_list<MODE>()) {
+        if ((var & (SPH_VAR_RING | 7)) == (SPH_VAR_RING | 5)) rc = launch_brick_cfg<MODE, CfgR, SPH_VAR_RING | SPH_VAR_PAD | SPH_VAR_MICRO>(c);
+        else if ((var & (SPH_VAR_PAD | SPH_VAR_MICRO)) == (SPH_VAR_PAD | SPH_VAR_MICRO)) rc = launch_brick_cfg<MODE, Cfg0, SPH_VAR_PAD | SPH_VAR_MICRO>(c);
+        else rc = launch_brick_cfg<MODE, Cfg0>(c);
+    } else
         rc = launch_brick_cfg<MODE, Cfg0>(c);
     if (!rc && mode_writes_list<MODE>()) { c->lists_valid = true; c->stg_kind = 2; c->k_kind = 0; }
     if (!rc && MODE == GM_DF_DENSITY_CHANGE) c->k_kind = 1;

@@ -80,7 +80,7 @@ struct SphContext {
     hipEvent_t ev_fork;  // main stream -> side stream hand-off in sph_slab_forces
     hipStream_t side;    // slab mode: boundary force sweep + halo packers run here, concurrently with the interior sweep
     bool use_side;       // launchers enqueue on `side` (with their own brick list) while this is set
-    int* brick_list2;    // [brick_cap] brick list of launches on the side stream
+    int2* brick_list2;   // [brick_cap] brick list of launches on the side stream
     int* brick_count2;
     int off_zero_mask;   // which of the pending offsets are layer 0 (no copy needed)
     int tgt_layers[4];  // density lo/hi, force lo/hi (slab mode); default 0..nx
@@ -105,7 +105,7 @@ struct SphContext {
     int* scan_sums;    // block sums for the scan
     unsigned short* glist;  // [SPH_GLIST_ROWS * cap] neighbour lists handed from the density to the force sweep
     unsigned char* gcnt;    // [cap] list lengths (255 = take the global cell walk)
-    int* brick_list;        // [brick_cap] non-empty bricks of the sweep being launched
+    int2* brick_list;       // [brick_cap] bricks of the sweep being launched: (column group, first z layer | height << 16)
     int* brick_count;       // device counter
     int brick_cap;
     int scan_blocks;
@@ -126,7 +126,7 @@ struct SphContext {
                         // GM_DENSITY_EOS, 2 the DFSPH record (x, y, z, +m_V fluid / -m_V solid) of GM_DF_DENSITY
     int k_kind;         // gat-as-float holds k_j = b_j * factor_j: 0 no, 1 b = density_adv, 2 b = density_adv - 1
     bool bricks_valid;  // brick_list/brick_count describe the current order for the target ranges in bricks_key
-    int bricks_key[5];  // brick shape id, tgt_lo, tgt_hi, tgt_lo2, tgt_hi2
+    int bricks_key[5];  // partition id (footprint, cut rule, limits), tgt_lo, tgt_hi, tgt_lo2, tgt_hi2
     double* h_df_err;   // pinned, device-visible: result of compute_density_error
     double* df_part;    // [SPH_DF_ERR_BLOCKS] per-workgroup partial sums
     SphDfsphParams df;  // DFSPH solver knobs

@@ -9,7 +9,7 @@ import scenes
 
 pytestmark = pytest.mark.gpu
 
-IMPLS = [(0, 0), (1, 0), (1, 1), (1, 2), (1, 3)]      # (gather_impl, brick_shape)
+IMPLS = [(0, 0), (1, 0), (1, 1)]      # (gather_impl, brick partition: 0 = adaptive height, 1 = fixed 4x2x4)
 F_TOL = {"m_V": 2e-5, "density": 2e-5, "pressure": 5e-5, "acceleration": 1e-4, "v": 2e-5, "x": 2e-6}
 
 
@@ -95,7 +95,7 @@ def test_kernel_by_kernel(impl, shape):
     ps.close()
 
 
-@pytest.mark.parametrize("impl,shape,fused", [(0, 0, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (1, 2, 1), (1, 3, 1), (1, 0, 0)])
+@pytest.mark.parametrize("impl,shape,fused", [(0, 0, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (1, 0, 0)])
 @pytest.mark.parametrize("scene_fn", [scenes.fluid_only, scenes.fluid_with_rigid_blocks])
 def test_trajectory(scene_fn, impl, shape, fused):
     sd = scene_fn()

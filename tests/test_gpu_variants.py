@@ -8,7 +8,7 @@ import scenes
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 13, 16, 21, 24, 29, 31, 37, 61, 101, 125, 189]
+VARIANTS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 13, 16, 21, 24, 29, 31, 37, 61, 101, 125, 189, 261, 285]
 
 
 def _system(sd, arrays, variant):
@@ -41,7 +41,7 @@ def test_variant_follows_the_oracle(variant):
     ps.close()
 
 
-@pytest.mark.parametrize("variant", [1, 2, 4, 7, 15, 21, 31, 61, 125, 189])
+@pytest.mark.parametrize("variant", [1, 2, 4, 7, 15, 21, 31, 61, 125, 189, 285])
 def test_variant_on_crowded_cells(variant):
     """12^3 particles in a (1.5 h)^3 box: > 63 neighbours each, so every list overflows (the two-phase density must
     fall back to the exact walk; the range-checked list stores must drop rows >= LISTCAP and nothing else)."""
@@ -81,7 +81,7 @@ def test_variants_agree_with_each_other_on_a_ragged_lattice():
             assert err <= tol, f"variant {variant} vs 0: {n}: {err:.3e}"
 
 
-@pytest.mark.parametrize("variant", [0, 29, 61, 125, 189])
+@pytest.mark.parametrize("variant", [0, 29, 61, 125, 189, 285])
 def test_long_lists_between_64_and_95_entries(variant):
     """A slab compressed to ~2.5 x rest density (spacing 0.74 d): 65..95 list entries per interior particle -- beyond
     the 63 of round 1, inside LISTCAP = 95 -- so the list rows >= 64 are written by the density sweep and read back

@@ -47,10 +47,13 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--settle", type=int, default=2000)
     ap.add_argument("--settled-steps", type=int, default=60)
+    ap.add_argument("--shapes", default="0", help="SPH_OPT_BRICK_SHAPE values to cross the variants with (0 = adaptive height, 1 = fixed 4x2x4)")
+    ap.add_argument("--dump-settled", default="", help="write the settled positions (float32 [N,3], by pid) to this .npy")
     ap.add_argument("--out", default="gpurun_out/variants.json")
     a = ap.parse_args()
     from sph_taichi_amd import ParticleSystem, SimConfig, _lib
     variants = [int(v) for v in a.variants.split(",")]
+    shapes = [int(v) for v in a.shapes.split(",")]
     sd = bench.scene_dict(a.workload)
     out = {"workload": a.workload, "steps": a.steps, "settle": a.settle, "rest": {}, "settled": {}}
 
@@ -60,21 +63,29 @@ def main():
         solver.initialize()
         return ps, solver
 
-    for v in variants:
+    combos = [(sh, v) for sh in shapes for v in variants]
+    name = lambda sh, v: str(v) if shapes == [0] else f"shape{sh}_var{v}"
+    for sh, v in combos:
         ps, solver = fresh()
+        ps.set_option(_lib.OPT_BRICK_SHAPE, sh)
         ps.set_option(_lib.OPT_KERNEL_VARIANT, v)
-        out["rest"][str(v)] = timed(ps, solver, _lib, a.steps, 5)
-        print(f"[rest] variant {v:2d}: {out['rest'][str(v)]}", flush=True)
+        out["rest"][name(sh, v)] = timed(ps, solver, _lib, a.steps, 5)
+        print(f"[rest] shape {sh} variant {v:3d}: {out['rest'][name(sh, v)]}", flush=True)
         ps.close()
     if a.settle > 0:
         ps, solver = fresh()
         solver.step(a.settle)
         ps.sync()
-        for v in variants + [variants[0]]:
+        if a.dump_settled:
+            import numpy as np
+            x = ps.x.to_numpy()
+            np.save(a.dump_settled, x.astype(np.float32))
+        for sh, v in combos + [combos[0]]:
+            ps.set_option(_lib.OPT_BRICK_SHAPE, sh)
             ps.set_option(_lib.OPT_KERNEL_VARIANT, v)
-            key = str(v) if str(v) not in out["settled"] else f"{v}_again"
+            key = name(sh, v) if name(sh, v) not in out["settled"] else f"{name(sh, v)}_again"
             out["settled"][key] = timed(ps, solver, _lib, a.settled_steps, 3)
-            print(f"[settled {a.settle}] variant {v:2d}: {out['settled'][key]}", flush=True)
+            print(f"[settled {a.settle}] shape {sh} variant {v:3d}: {out['settled'][key]}", flush=True)
         st = _lib.SphStats()
         ps._call("sph_get_stats", st)
         out["settled_neighbourhood"] = {"mean_list_entries": round(st.list_entries / max(st.targets, 1), 2),

@@ -43,13 +43,14 @@ DevView sph_view(const SphContext* c) {
     }
     const int o = c->in_off;
     d.xm = c->xm[c->cur] + o; d.vf = c->vf[c->cur] + o; d.aux = c->aux[c->cur] + o; d.key = c->key[c->cur] + o;
-    d.eos = c->eos; d.acc = c->acc + o; d.cell_end = c->cell_end;
+    d.eos = c->eos; d.eos2 = reinterpret_cast<float2*>(c->eos); d.acc = c->acc + o; d.cell_end = c->cell_end;
     d.x0_cold = c->x0_cold; d.rigid_rest_cm = c->rigid_rest_cm;
     d.m_eps = c->df.m_eps;
     d.stg = c->stg; d.gat = c->gat; d.kbuf = reinterpret_cast<float*>(c->gat);
     d.m_u = c->m_uniform; d.write_sg = 0; d.write_k = 0;
     d.whx = p.wall_hi[0]; d.why = p.wall_hi[1]; d.whz = p.wall_hi[2];
     d.fuse_advect = c->fuse_advect;
+    d.store_acc = !(c->fuse_advect && c->skip_acc);
     return d;
 }
 
@@ -284,6 +285,7 @@ int32_t sph_set_particle_count(SphContext* c, int32_t n) {
     c->N = n;
     c->n_dyn_host = -1;
     sph_invalidate_lists(c);
+    c->aux_stale = false;
     c->have_keys = c->have_prefix = false;
     return 0;
 }
@@ -304,6 +306,7 @@ int32_t sph_upload(SphContext* c, int32_t field, const void* host, size_t bytes)
     if (bytes != field_bytes(c, field)) return sph_fail(c, SPH_E_INVALID, "sph_upload: size mismatch");
     SPH_HIP(c, hipSetDevice(c->device));
     if (bytes == 0) return 0;
+    if (field == SPH_F_DENSITY || field == SPH_F_PRESSURE) { int rc0 = sph_ensure_aux(c); if (rc0) return rc0; }
     if (field == SPH_F_RIGID_REST_CM) {
         SPH_HIP(c, hipMemcpyAsync(c->rigid_rest_cm, host, bytes, hipMemcpyHostToDevice, c->stream));
         SPH_HIP(c, hipStreamSynchronize(c->stream));
@@ -329,7 +332,8 @@ int32_t sph_download(SphContext* c, int32_t field, void* host, size_t bytes) {
     if (field == SPH_F_GRID_PARTICLES_NUM) src = c->cell_end;
     else if (field == SPH_F_RIGID_REST_CM) src = c->rigid_rest_cm;
     else {
-        int rc = sphk_extract(c, field, c->stage);
+        int rc = (field == SPH_F_DENSITY || field == SPH_F_PRESSURE) ? sph_ensure_aux(c) : 0;
+        rc = rc ? rc : sphk_extract(c, field, c->stage);
         if (rc) return rc;
     }
     SPH_HIP(c, hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -386,12 +390,14 @@ static int counting_sort(SphContext* c, bool sort_acc) {
 
 int32_t sph_counting_sort(SphContext* c) {
     ENTER(c);
-    return counting_sort(c, true);
+    int rc = sph_ensure_aux(c);  // the reference's sort carries density and pressure along (particle_system.py:332-369)
+    return rc ? rc : counting_sort(c, true);
 }
 
 int32_t sph_initialize_particle_system(SphContext* c) {
     ENTER(c);
-    int rc = sph_update_grid_id(c);
+    int rc = sph_ensure_aux(c);
+    rc = rc ? rc : sph_update_grid_id(c);
     rc = rc ? rc : sph_prefix_sum(c);
     rc = rc ? rc : counting_sort(c, true);
     return rc;
@@ -421,12 +427,14 @@ int32_t sph_compute_densities(SphContext* c) {
 int32_t sph_compute_non_pressure_forces(SphContext* c) {
     ENTER(c);
     int rc = need_sorted(c, "sph_compute_non_pressure_forces");
+    rc = rc ? rc : sph_ensure_aux(c);
     return rc ? rc : sphk_gather(c, GM_NONPRESSURE);
 }
 
 int32_t sph_compute_pressure_forces(SphContext* c) {
     ENTER(c);
     int rc = need_sorted(c, "sph_compute_pressure_forces");
+    rc = rc ? rc : sph_ensure_aux(c);
     rc = rc ? rc : sphk_eos(c);                      // WCSPH.py:71-76
     return rc ? rc : sphk_gather(c, GM_PRESSURE);    // WCSPH.py:77-85
 }
@@ -611,7 +619,9 @@ int32_t sph_step(SphContext* c, int32_t n_steps, const int32_t* dynamic_ids, int
         rc = rc ? rc : counting_sort(c, false);  // acceleration is dead here: every particle's a is rewritten below
         if (rc) return rc;
         if (timing) SPH_HIP(c, hipEventRecord(ev[1], c->stream));
+        c->skip_acc = it + 1 < n_steps;  // only the acceleration of the call's last step can ever be read
         rc = step_sweeps(c, ev, dynamic_ids, n_dynamic);
+        c->skip_acc = 0;
         if (rc) return rc;
         if (timing) { SPH_HIP(c, hipEventRecord(ev[4], c->stream)); c->ev_used++; }
     }
@@ -690,6 +700,7 @@ int32_t sph_select_range(SphContext* c, int32_t first, int32_t count) {
     c->in_off += first;
     c->N = count;
     sph_invalidate_lists(c);
+    c->aux_stale = false;  // (eos2 is indexed from the old first record)
     c->have_keys = c->have_prefix = c->sorted = false;
     c->n_dyn_host = -1;
     return 0;

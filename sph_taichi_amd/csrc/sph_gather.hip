@@ -92,10 +92,12 @@ __device__ __forceinline__ float4 make_C_from_aux(const float4 aux) {
 template <int MODE>
 __device__ __forceinline__ float4 target_load_E(const DevView& d, int i) {
     // (GM_DENSITY_EOS: the aux record its finish rewrites -- requested with the target's other records, so that the
-    // finish does not end every brick with a load it has to wait for)
-    if (MODE == GM_NONPRESSURE || MODE == GM_PRESSURE || MODE == GM_DENSITY_EOS) return d.aux[i];
-    if (MODE == GM_FORCE_FUSED || MODE == GM_FORCE_FUSED_U || mode_is_df_iter<MODE>() || mode_is_df_vdiv<MODE>() ||
-        MODE == GM_DF_NONPRESSURE)
+    // finish does not end every brick with a load it has to wait for; the lean finish of the uniform-fluid step
+    // (write_sg) neither reads nor writes aux)
+    if (MODE == GM_DENSITY_EOS) return d.write_sg ? make_float4(0.f, 0.f, 0.f, 0.f) : d.aux[i];
+    if (MODE == GM_NONPRESSURE || MODE == GM_PRESSURE) return d.aux[i];
+    if (MODE == GM_FORCE_FUSED_U) { const float2 e = d.eos2[i]; return make_float4(e.x, e.y, 0.f, 0.f); }  // lean record (p, rho)
+    if (MODE == GM_FORCE_FUSED || mode_is_df_iter<MODE>() || mode_is_df_vdiv<MODE>() || MODE == GM_DF_NONPRESSURE)
         return d.eos[i];
     return make_float4(0.f, 0.f, 0.f, 0.f);
 }
@@ -116,11 +118,16 @@ __device__ __forceinline__ void target_init(const DevView& d, Target& t, const f
         t.st_c = d.sigma / E.x;     // WCSPH.py:100
         t.dpj_solid = E.z / (d.rho0 * d.rho0);
     }
-    if (MODE == GM_FORCE_FUSED || MODE == GM_FORCE_FUSED_U) {
+    if (MODE == GM_FORCE_FUSED) {
         t.dpi = E.x; t.m = E.z; t.rho = E.w;
         t.p = E.x * (E.w * E.w);
         t.st_c = d.sigma / E.z;
-        if (MODE == GM_FORCE_FUSED_U) t.st_c = t.st_c * d.m_u;  // (sigma / m_i) * m_j with the common m_j (WCSPH.py:100)
+        t.dpj_solid = t.p / (d.rho0 * d.rho0);
+    }
+    if (MODE == GM_FORCE_FUSED_U) {  // lean record E = (p, rho); p / rho^2 exactly as the density finish wrote it into gat
+        t.p = E.x; t.rho = E.y; t.m = d.m_u;
+        t.dpi = E.x * __builtin_amdgcn_rcpf(E.y * E.y);
+        t.st_c = (d.sigma / d.m_u) * d.m_u;  // (sigma / m_i) * m_j with the common mass (WCSPH.py:100)
         t.dpj_solid = t.p / (d.rho0 * d.rho0);
     }
     if (MODE == GM_BVOL_STATIC || MODE == GM_BVOL_DYNAMIC) t.s0 = d.w_zero;  // sph_base.py:95, 110
@@ -381,32 +388,42 @@ __device__ __forceinline__ void target_finish(const DevView& d, Target& t, int i
         return;
     }
     if (MODE == GM_DENSITY_EOS) {
-        float4 aux = E;  // = d.aux[i], loaded by the caller (target_load_E)
-        float4 e;
+        float rho_raw = 0.0f, rho = 0.0f, p = 0.0f;
         if (gathered) {
-            float rho_raw = (t.self_in_sum ? t.s0 : t.mV * d.w_zero + t.s0) * d.rho0;  // WCSPH.py:39-43
+            rho_raw = (t.self_in_sum ? t.s0 : t.mV * d.w_zero + t.s0) * d.rho0;  // WCSPH.py:39-43
             if (d.ablate & (1 | 16 | 32)) rho_raw = d.rho0;  // profiling runs that skip pair terms: keep the state finite
-            const float rho = fmaxf(rho_raw, d.rho0);                 // WCSPH.py:75
+            rho = fmaxf(rho_raw, d.rho0);                 // WCSPH.py:75
             // WCSPH.py:76 ti.pow(rho / rho0, exponent): integer exponents by multiplication (sph_tait_pow); the ratio is
             // the IEEE quotient (once per particle; its error is amplified by stiffness * exponent), the later
             // divisions are reciprocals.  Exactly 0 at rho = rho0, where most of a resting fluid sits after the clamp.
             const float xr = rho / d.rho0;
-            const float p = d.stiffness * (sph_tait_pow<true>(d, xr) - 1.0f);
+            p = d.stiffness * (sph_tait_pow<true>(d, xr) - 1.0f);
+        } else {
+            // WCSPH.py:131-137 for non-fluid particles: static a = 0, dynamic rigid a = g
+            const bool st = sph_is_static_rigid(t.flags);
+            d.acc[i] = st ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(d.gx, d.gy, d.gz, 0.f);
+        }
+        if (d.write_sg) {
+            // Uniform-fluid step (every fluid particle has mass m_u and m_V0; positions do not change before the force
+            // sweep runs): what that sweep needs of a NEIGHBOUR goes to stg (staged in LDS) and gat (gathered), what it
+            // needs of the TARGET besides those to the 8-byte record (p, rho).  aux is neither read nor written here:
+            // density and pressure are folded into it from eos2 when somebody asks (sph_ensure_aux).
+            const bool fl = sph_is_fluid(t.flags);
+            if (gathered) d.eos2[i] = make_float2(p, rho);
+            d.stg[i] = make_float4(t.x, t.y, t.z, fl ? d.m_u * sph_rcp(rho_raw) : -t.mV);
+            d.gat[i] = make_float4(t.vx, t.vy, t.vz, fl ? p * sph_rcp(rho * rho) : (sph_is_dynamic_rigid(t.flags) ? 1.0f : 0.0f));
+            return;
+        }
+        float4 aux = E;  // = d.aux[i], loaded by the caller (target_load_E)
+        float4 e;
+        if (gathered) {
             e = make_float4(p * sph_rcp(rho * rho), aux.x * sph_rcp(rho_raw), aux.x, rho);
             aux.y = rho; aux.z = p;
             d.aux[i] = aux;
         } else {
             e = make_float4(0.0f, 0.0f, aux.x, aux.y);
-            // WCSPH.py:131-137 for non-fluid particles: static a = 0, dynamic rigid a = g
-            const bool st = sph_is_static_rigid(t.flags);
-            d.acc[i] = st ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(d.gx, d.gy, d.gz, 0.f);
         }
         d.eos[i] = e;
-        if (d.write_sg) {  // records of the uniform-fluid force sweep (positions do not change before it runs)
-            const bool fl = sph_is_fluid(t.flags);
-            d.stg[i] = make_float4(t.x, t.y, t.z, fl ? e.y : -t.mV);
-            d.gat[i] = make_float4(t.vx, t.vy, t.vz, fl ? e.x : (sph_is_dynamic_rigid(t.flags) ? 1.0f : 0.0f));
-        }
         return;
     }
     if (MODE == GM_NONPRESSURE || MODE == GM_DF_NONPRESSURE) {
@@ -472,7 +489,7 @@ __device__ __forceinline__ void target_finish(const DevView& d, Target& t, int i
         // fluid: a = (g + non-pressure) + pressure  (WCSPH.py:140 then :85)
         if (gathered) {
             const float4 a = make_float4(t.ax + t.px, t.ay + t.py, t.az + t.pz, 0.f);
-            d.acc[i] = a;
+            if (MODE != GM_FORCE_FUSED_U || d.store_acc) d.acc[i] = a;
             if (MODE == GM_FORCE_FUSED_U && d.fuse_advect) {  // advect (WCSPH.py:143-149) + fluid walls, see step_sweeps
                 float4 xm = make_float4(t.x, t.y, t.z, t.mV);
                 float4 vf = make_float4(t.vx, t.vy, t.vz, __int_as_float(t.flags));
@@ -604,7 +621,7 @@ __global__ __launch_bounds__(TPB) void k_gather_bvol_split(DevView d, const int*
 // are dropped by the buffer's range check, and an offset stuck at 2^32 - 1 stays out of range); the list readers form
 // the offsets of up to 8 rows past a list's end before clamping them.
 #define SPH_VOFF_ROWS (SPH_GLIST_ROWS + 8)
-#define SPH_BRICK_MAX_NZ 1000  // k_brick_list keeps four per-layer arrays per column group in LDS; taller grids take the cell walk
+#define SPH_BRICK_MAX_NZ 1000  // k_brick_list keeps five per-layer arrays per column group in LDS; taller grids take the cell walk
 #define SPH_CNT_WALK 255  // gcnt sentinel: this target must take the exact global cell walk (its brick's shell overflowed the LDS tile)
 #define SPH_CNT_LIST_OVF 254  // same consequence, other cause: the target's own list outgrew LISTCAP
 
@@ -670,33 +687,39 @@ __global__ __launch_bounds__(TPB) void k_brick_list(DevView d, int nbx, int nby,
     __shared__ int s_base[2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nz = d.nz;
-    int* Sp = sm_bl + wave * 4 * (nz + 1);  // [nz + 1] shell records in layers [0, z) of the column group's shell columns
+    int* Sp = sm_bl + wave * 5 * (nz + 1);  // [nz + 1] shell records in layers [0, z) of the column group's shell columns
     int* Tp = Sp + (nz + 1);                // [nz + 1] targets in layers [0, z)
-    int* bz = Tp + (nz + 1);                // bricks of this column group: first layer | height << 16
+    int* Ex = Tp + (nz + 1);                // [nz] height of the brick that would start at layer z (0: no target there)
+    int* bz = Ex + (nz + 1);                // bricks of this column group: first layer | height << 16
     int* bt = bz + (nz + 1);                //                              targets
     const int cg = blockIdx.x * (TPB / 64) + wave;
     const bool live = cg < nbx * nby;
     const int bxi = cg / nby, byi = cg % nby;
     const int cx0 = bxi * CFG::BX, cy0 = byi * CFG::BY;
-    const int cx1 = min(cx0 + CFG::BX, d.nx), cy1 = min(cy0 + CFG::BY, d.ny);  // excl.
-    const int sx0 = max(cx0 - 1, 0), sy0 = max(cy0 - 1, 0);
-    const int sx1 = min(cx1, d.nx - 1), sy1 = min(cy1, d.ny - 1);  // incl.
     int carryS = 0, carryT = 0;
     if (live && lane == 0) { Sp[0] = 0; Tp[0] = 0; }
     for (int zb = 0; zb < nz; zb += 64) {
         const int z = zb + lane;
+        // all (BX + 2) (BY + 2) columns' loads are issued before the first is used (a loop over the columns that waits
+        // for each pair of loads made this kernel three times as long as the one-lane-per-brick kernel it replaced)
+        int hi_[CFG::NCOL], lo_[CFG::NCOL];
+#pragma unroll
+        for (int c = 0; c < CFG::NCOL; ++c) {
+            const int ix = cx0 - 1 + c / (CFG::BY + 2), iy = cy0 - 1 + c % (CFG::BY + 2);
+            const bool ok = live && z < nz && ix >= 0 && ix < d.nx && iy >= 0 && iy < d.ny;
+            const int f = ok ? sph_flatten(d, ix, iy, z) : 0;
+            hi_[c] = ok ? d.cell_end[f] : 0;
+            lo_[c] = (ok && f > 0) ? d.cell_end[f - 1] : 0;
+        }
         int s_ = 0, t_ = 0;
-        if (live && z < nz) {
-            for (int ix = sx0; ix <= sx1; ++ix) {
-                const bool tx = ix >= cx0 && ix < cx1 &&
-                                ((ix >= d.tgt_lo && ix < d.tgt_hi) || (ix >= d.tgt_lo2 && ix < d.tgt_hi2));
-                for (int iy = sy0; iy <= sy1; ++iy) {
-                    const int f = sph_flatten(d, ix, iy, z);
-                    const int n = d.cell_end[f] - (f > 0 ? d.cell_end[f - 1] : 0);
-                    s_ += n;
-                    if (tx && iy >= cy0 && iy < cy1) t_ += n;
-                }
-            }
+#pragma unroll
+        for (int c = 0; c < CFG::NCOL; ++c) {
+            const int ix = cx0 - 1 + c / (CFG::BY + 2), iy = cy0 - 1 + c % (CFG::BY + 2);
+            const int n = hi_[c] - lo_[c];
+            s_ += n;
+            const bool tgt = ix >= cx0 && ix < cx0 + CFG::BX && iy >= cy0 && iy < cy0 + CFG::BY &&
+                             ((ix >= d.tgt_lo && ix < d.tgt_hi) || (ix >= d.tgt_lo2 && ix < d.tgt_hi2));
+            t_ += tgt ? n : 0;
         }
         const int si = sph_wave_inclusive_scan(s_, lane), ti = sph_wave_inclusive_scan(t_, lane);
         if (live && z < nz) { Sp[z + 1] = carryS + si; Tp[z + 1] = carryT + ti; }
@@ -704,24 +727,35 @@ __global__ __launch_bounds__(TPB) void k_brick_list(DevView d, int nbx, int nby,
         carryT += __shfl(ti, 63, 64);
     }
     __syncthreads();
+    // every layer: how high would a brick starting here be?
+    if (live)
+        for (int z = lane; z < nz; z += 64) {
+            int e = 0;
+            const int t0 = Tp[z];
+            if (Tp[z + 1] != t0) {
+                if (fixed_bz > 0) {
+                    e = min(fixed_bz - z % fixed_bz, nz - z);
+                } else {
+                    const int s0 = Sp[max(z - 1, 0)];
+                    e = 1;
+                    while (z + e < nz && e < CFG::BZ && Tp[z + e + 1] != Tp[z + e] && Tp[z + e + 1] - t0 <= tmax &&
+                           Sp[min(z + e + 2, nz)] - s0 <= smax)
+                        ++e;
+                }
+            }
+            Ex[z] = e;
+        }
+    __syncthreads();
     int nb = 0;
     if (live && lane == 0) {
         int z = 0;
         while (z < nz) {
-            if (Tp[z + 1] == Tp[z]) { ++z; continue; }  // no target in this layer
-            int z1;
-            if (fixed_bz > 0) {
-                z = (z / fixed_bz) * fixed_bz;
-                z1 = min(z + fixed_bz, nz);
-            } else {
-                z1 = z + 1;
-                while (z1 < nz && z1 - z < CFG::BZ && Tp[z1 + 1] != Tp[z1]) {
-                    if (Tp[z1 + 1] - Tp[z] > tmax || Sp[min(z1 + 2, nz)] - Sp[max(z - 1, 0)] > smax) break;
-                    ++z1;
-                }
-            }
-            bz[nb] = z | ((z1 - z) << 16);
-            bt[nb] = Tp[z1] - Tp[z];
+            const int e = Ex[z];
+            if (e == 0) { ++z; continue; }
+            const int z0 = fixed_bz > 0 ? (z / fixed_bz) * fixed_bz : z;  // fixed partition: bricks aligned to multiples of fixed_bz
+            const int z1 = z + e;
+            bz[nb] = z0 | ((z1 - z0) << 16);
+            bt[nb] = Tp[z1] - Tp[z0];
             ++nb;
             z = z1;
         }
@@ -1380,6 +1414,27 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
     }
 }
 
+// density / pressure of the fluid from the lean record (p, rho) of the uniform-fluid step into aux (sph_ensure_aux)
+__global__ __launch_bounds__(TPB) void k_aux_from_eos2(DevView d) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= d.N) return;
+    if (!sph_is_fluid(__float_as_int(d.vf[i].w))) return;
+    const float2 e = d.eos2[i];
+    float* a = reinterpret_cast<float*>(&d.aux[i]);
+    a[1] = e.y;
+    a[2] = e.x;
+}
+
+int sph_ensure_aux(SphContext* c) {
+    if (!c->aux_stale) return 0;
+    c->aux_stale = false;
+    if (c->N <= 0) return 0;
+    DevView d = sph_view(c);
+    hipLaunchKernelGGL(k_aux_from_eos2, dim3((c->N + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d);
+    SPH_LAUNCH_CHECK(c);
+    return 0;
+}
+
 // EOS alone (first loop of compute_pressure_forces, WCSPH.py:71-76)
 __global__ __launch_bounds__(TPB) void k_eos(DevView d) {
     const int i = blockIdx.x * TPB + threadIdx.x;
@@ -1449,7 +1504,7 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
     if (c->use_side || !c->bricks_valid || (memcmp(key, c->bricks_key, sizeof(key)) != 0 && !subset)) {
         if (c->use_side || !c->brick_count_zero) SPH_HIP(c, hipMemsetAsync(bcount, 0, 2 * sizeof(int), st));
         if (!c->use_side) c->brick_count_zero = false;
-        hipLaunchKernelGGL((k_brick_list<CFG>), dim3((ncg + TPB / 64 - 1) / (TPB / 64)), dim3(TPB), (size_t)(TPB / 64) * 4 * (d.nz + 1) * sizeof(int),
+        hipLaunchKernelGGL((k_brick_list<CFG>), dim3((ncg + TPB / 64 - 1) / (TPB / 64)), dim3(TPB), (size_t)(TPB / 64) * 5 * (d.nz + 1) * sizeof(int),
                            st, d, nbx, nby, blist, bcount, c->brick_cap, tmax, smax, fixed_bz);
         SPH_LAUNCH_CHECK(c);
         if (!c->use_side) {  // (the side stream's list is private to that launch and never cached)
@@ -1516,7 +1571,7 @@ static int launch_sweep(SphContext* c) {
     if (c->opt_gather_impl == 0 || c->p.grid_num[2] > SPH_BRICK_MAX_NZ) return launch_simple<MODE>(c, nullptr, c->N);
     int rc = launch_brick<MODE>(c);
     if (!rc && mode_writes_list<MODE>()) c->lists_valid = true;
-    if (!rc && MODE == GM_DENSITY_EOS) c->stg_kind = c->uniform_state == 1 ? 1 : 0;
+    if (!rc && MODE == GM_DENSITY_EOS) { c->stg_kind = c->uniform_state == 1 ? 1 : 0; if (c->stg_kind == 1) c->aux_stale = true; }
     return rc;
 }
 
@@ -1549,6 +1604,11 @@ static int launch_df(SphContext* c) {
 }
 
 int sphk_gather(SphContext* c, int mode) {
+    // every sweep but the fused step's own pair reads or rewrites density / pressure in aux
+    if (c->aux_stale && mode != GM_DENSITY_EOS && mode != GM_FORCE_FUSED && mode != GM_BVOL_STATIC && mode != GM_BVOL_DYNAMIC) {
+        int rc = sph_ensure_aux(c);
+        if (rc) return rc;
+    }
     switch (mode) {
         case GM_BVOL_STATIC: return launch_simple<GM_BVOL_STATIC>(c, nullptr, c->N);  // init only
         case GM_BVOL_DYNAMIC: {

@@ -50,10 +50,13 @@ struct DevView {
     int fuse_advect;    // GM_FORCE_FUSED_U finish also integrates its fluid targets (WCSPH.py:143-149 + fluid walls)
     int write_sg;       // density finish also writes the stg (/ gat) records of the one-gather sweeps
     int write_k;        // density-change / -advection finish also writes k_j into kbuf
+    int store_acc;      // GM_FORCE_FUSED_U finish with the fused advect: also store the acceleration (0: a step inside
+                        // sph_step(n) that is not the last -- nothing can read the field before the next step rewrites it)
     float4* xm;
     float4* vf;
     float4* aux;
     float4* eos;
+    float2* eos2; // lean target record (p, rho) of the uniform-fluid WCSPH step (same memory as eos)
     float4* stg;  // (x, y, z, U): U = m/rho_raw (fluid, > 0) or -m_V (solid)      } uniform-fluid force path:
     float4* gat;  // (vx, vy, vz, p/rho^2) (fluid) or (v, 1 if dynamic else 0) (solid) } staged / gathered records
     float* kbuf;  // DFSPH: k_j = b_j * dfsph_factor_j (same memory as gat)
@@ -91,6 +94,7 @@ struct SphContext {
     float4* aux[2];
     int* key[2];
     float4* eos;
+    float2* eos2; // lean target record (p, rho) of the uniform-fluid WCSPH step (same memory as eos)
     float4* stg;
     float4* gat;
     float4* acc;
@@ -137,6 +141,9 @@ struct SphContext {
     int opt_sort_by_pid;
     int opt_variant;     // SPH_OPT_KERNEL_VARIANT (bit mask of SPH_VAR_*)
     int fuse_advect;     // set around the force launch of sph_step when the advect can ride in its finish
+    int skip_acc;        // set by sph_step for every step but the last of a call: the fused force finish keeps its acceleration to itself
+    bool aux_stale;      // density / pressure of the fluid live in eos2 (written by the lean density finish), not yet in aux:
+                         // sph_ensure_aux folds them in before anything reads aux.y / aux.z or a reference-API sort moves the records
     int opt_uniform;     // SPH_OPT_UNIFORM_FLUID: -1 auto, 0 off, 1 check once
     int uniform_state;   // -1 unknown, 0 the precondition fails, 1 holds (m_uniform valid)
     float m_uniform;
@@ -178,6 +185,7 @@ int sphk_gather(SphContext* c, int mode);
 int sphk_gather_layers(SphContext* c, int mode, int lo, int hi, int lo2, int hi2);  // brick sweep, targets in x layers [lo,hi) u [lo2,hi2)
 int sphk_pack_advected(SphContext* c, int first, int count, void* dst);
 int sphk_eos(SphContext* c);
+int sph_ensure_aux(SphContext* c);  // materialise density / pressure in aux if the lean density finish left them in eos2
 int sphk_stats(SphContext* c, SphStats* out);  // synchronises
 int sphk_check_uniform_fluid(SphContext* c);  // sets uniform_state / m_uniform (synchronises)
 int sphk_df_density_error(SphContext* c, float offset, float* out_host);

@@ -208,6 +208,7 @@ int sphk_sort_scatter(SphContext* c, bool sort_acc) {
     c->brick_count_zero = true;
     c->cur = o;
     sph_invalidate_lists(c);
+    c->aux_stale = false;  // (eos2 is in the old order: whoever needed density / pressure called sph_ensure_aux before)
     if (sort_acc) {
         float4* t = c->acc;
         c->acc = c->acc_tmp;

@@ -154,6 +154,12 @@ def main():
     ap.add_argument("--settle", type=int, default=0,
                     help="run this many untimed steps first, so that the timed ones see a developed flow (dam-break front, "
                          "sloshing, compression at the walls) instead of the initial lattice")
+    ap.add_argument("--settled-after", type=int, default=2000,
+                    help="the default line also times the box after this many further untimed steps (`settled` object); 0 = skip")
+    ap.add_argument("--min-seconds", type=float, default=0.5,
+                    help="each state is timed for at least this long: from rest by repeating the K-step block from the re-uploaded "
+                         "initial state (`reps`), settled as one longer block")
+    ap.add_argument("--max-reps", type=int, default=80)
     ap.add_argument("--recut-every", type=int, default=0,
                     help="--gpus N: re-cut the slabs every K steps (0 = never: the tiled workload is balanced by construction)")
     ap.add_argument("--gather-impl", type=int, default=1)
@@ -277,33 +283,12 @@ def main():
         line["cpu_baseline"] = cpu_baseline(sd, args.cpu_steps) if args.cpu_steps > 0 else None
         print(json.dumps(line), flush=True)
         return
-    dt, tm = run(args.gather_impl, args.brick_shape, args.fused, args.steps, args.warmup)
-    k = max(int(tm.steps), 1)
-    ms_per_step = dt / args.steps * 1e3
-    steps_per_s = args.steps / dt
-    value = steps_per_s * N / REF_PARTICLES
-    force_ms = tm.force_ms / k
-    neigh_ms = tm.neighbour_ms / k
-    # Per-launch algorithmic bytes: density+EOS sweep 32 N + 4 G, fused force sweep 60 N + 4 G.  With no
-    # dynamic rigid body each phase is exactly one launch, so the HIP-event phase time is that kernel's duration.
-    kernels = {
-        "k_gather_brick<GM_DENSITY_EOS>": (32.0 * N + 4.0 * G, neigh_ms),
-        "k_gather_brick<GM_FORCE_FUSED>": (60.0 * N + 4.0 * G, force_ms),
-    }
-    one_gather = ps.get_option(_lib.OPT_UNIFORM_FLUID_STATE) == 1 and args.fused == 1
-    if one_gather:      # the force sweep that actually ran (SPH_OPT_UNIFORM_FLUID: all fluid masses equal)
-        kernels["k_gather_brick<GM_FORCE_FUSED_U>"] = kernels.pop("k_gather_brick<GM_FORCE_FUSED>")
-    if not args.gather_impl:
-        kernels = {k_.replace("brick", "simple"): v for k_, v in kernels.items()}
-    dominant = max(kernels, key=lambda k_: kernels[k_][1])
-    alg_bytes, dom_ms = kernels[dominant]
-    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    # ---- the headline line: state A = from rest, state B = the same box settled ----
     # Counter-derived figures (HBM bytes, VALU instruction counts) come from the committed rocprofv3 PMC passes
     # (profiles/pmc_traffic.json, tools/gpu_pmc.sh + tools/refresh_pmc.py).  They are quoted ONLY when that file was
     # measured on the kernel sources this library was built from (same fingerprint), on this workload and variant;
     # otherwise they are null -- never a number from another revision next to a live launch time.
-    traffic = valu_busy = None
-    pmc_k = {}
+    pmc_states = {}
     pmc_note = "no PMC file for this revision"
     try:
         from sph_taichi_amd import build as _build
@@ -314,69 +299,154 @@ def main():
                   and args.variant == -1 and args.settle == 0):
             pmc_note = "profiles/pmc_traffic.json covers the default line only (workload / variant / state differ): not quoted"
         else:
-            pmc_k = pm["kernels"]
-            kk = pmc_k[dominant]
-            traffic = kk["fetch_kb"] * 1024 * 2 + kk["write_kb"] * 1024
-            valu_busy = kk.get("valu_busy_frac")
+            pmc_states = pm.get("states") or {"rest": pm["kernels"]}
             pmc_note = f"profiles/pmc_traffic.json ({pm.get('source')}), same kernel fingerprint"
     except Exception as e:
         pmc_note = f"PMC file unusable ({type(e).__name__})"
+    one_gather = None
+    VALU_PEAK_GINST = 1024 * 2.4 / 2.0
+
+    def report(dt, tm, steps, state):
+        """value / breakdown / rooflines of one timed block (`state` selects the PMC table: "rest" or "settled")."""
+        nonlocal one_gather
+        k = max(int(tm.steps), 1)
+        ms_per_step = dt / steps * 1e3
+        force_ms, neigh_ms = tm.force_ms / k, tm.neighbour_ms / k
+        # Per-launch algorithmic bytes (SURVEY 8d): density+EOS sweep 32 N + 4 G, fused force sweep 60 N + 4 G.  With no
+        # dynamic rigid body each phase is one sweep launch (+ the brick-list kernel in the neighbour phase, ~12 us):
+        # the HIP-event phase time is an upper bound of the sweep's duration, the rocprofv3 kernel trace has the kernel alone.
+        kernels = {"k_gather_brick<GM_DENSITY_EOS>": (32.0 * N + 4.0 * G, neigh_ms),
+                   "k_gather_brick<GM_FORCE_FUSED>": (60.0 * N + 4.0 * G, force_ms)}
+        if one_gather is None:
+            one_gather = ps.get_option(_lib.OPT_UNIFORM_FLUID_STATE) == 1 and args.fused == 1
+        if one_gather:      # the force sweep that actually ran (SPH_OPT_UNIFORM_FLUID: all fluid masses equal)
+            kernels["k_gather_brick<GM_FORCE_FUSED_U>"] = kernels.pop("k_gather_brick<GM_FORCE_FUSED>")
+        if not args.gather_impl:
+            kernels = {k_.replace("brick", "simple"): v for k_, v in kernels.items()}
+        pmc_k = pmc_states.get(state, {})
+        rk = {}
+        for k_, (ab, ms) in kernels.items():
+            e = {"alg_bytes": ab, "avg_launch_ms": round(ms, 4), "achieved_GBs": round(ab / (ms * 1e-3) / 1e9, 2) if ms > 0 else 0.0,
+                 "frac_of_hbm_peak": round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 else 0.0,
+                 "traffic": None, "traffic_over_alg": None}
+            if k_ in pmc_k and "fetch_kb" in pmc_k[k_] and "write_kb" in pmc_k[k_]:
+                e["traffic"] = pmc_k[k_]["fetch_kb"] * 1024 * 2 + pmc_k[k_]["write_kb"] * 1024
+                e["traffic_over_alg"] = round(e["traffic"] / ab, 2)
+                if pmc_k[k_].get("valu_wave_insts") and ms > 0:
+                    wi = pmc_k[k_]["valu_wave_insts"]
+                    e["valu_wave_insts"] = wi
+                    e["valu_issue_frac"] = round(wi / (ms * 1e-3) / 1e9 / VALU_PEAK_GINST, 4)
+            rk[k_] = e
+        dominant = max(kernels, key=lambda k_: kernels[k_][1])
+        st = _lib.SphStats()
+        ps._call("sph_get_stats", st)
+        step_bytes = 360.0 * N + 20.0 * G
+        return {
+            "value": round(steps / dt * N / REF_PARTICLES, 3), "ms_per_step": round(ms_per_step, 4),
+            "steps_timed": steps,
+            "breakdown_ms": {"sort": round(tm.sort_ms / k, 4), "neighbour": round(neigh_ms, 4), "force": round(force_ms, 4),
+                             "integrate": round(tm.integrate_ms / k, 4), "sum_of_phases": round(tm.total_ms / k, 4)},
+            "dominant": dominant, "roofline_kernels": rk,
+            "roofline_step": {"alg_bytes": step_bytes, "achieved_GBs": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 2),
+                              "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "neighbourhood": {
+                "mean_list_entries": round(st.list_entries / max(st.targets - st.list_overflow_targets - st.lds_overflow_targets, 1), 2),
+                "max_list_entries": st.max_list, "list_overflow_targets": st.list_overflow_targets,
+                "lds_overflow_targets": st.lds_overflow_targets, "max_cell_occupancy": st.max_cell_occupancy,
+                "mean_cell_occupancy": round(N / max(st.nonempty_cells, 1), 2)},
+        }
+
+    # State A.  The contract's timed region: W untimed + exactly K timed steps.  K = 20 is 8 ms of GPU time, too short
+    # for anything outside this process to see, so the block is REPEATED from the same initial state (positions and
+    # velocities re-uploaded by persistent id, untimed) until >= 0.5 s of timed steps have run; the line reports the
+    # mean over the repetitions (`reps`) and the first one beside it.
+    import numpy as np
+    restore = args.settle == 0 and not args.ablate_mask
+    if restore:
+        x0, v0 = ps.x.to_numpy(), ps.v.to_numpy()
+        pid0 = ps.pid.to_numpy()
+        x_by_pid = np.empty_like(x0); x_by_pid[pid0] = x0
+        v_by_pid = np.empty_like(v0); v_by_pid[pid0] = v0
+    blocks = []
+    t_timed, reps = 0.0, 0
+    while True:
+        dt, tm = run(args.gather_impl, args.brick_shape, args.fused, args.steps, args.warmup)
+        blocks.append((dt, tm))
+        t_timed += dt
+        reps += 1
+        if not restore or t_timed >= args.min_seconds or reps >= args.max_reps:
+            break
+        pid = ps.pid.to_numpy()
+        ps.x.from_numpy(x_by_pid[pid]); ps.v.from_numpy(v_by_pid[pid])
+        solver.initialize()
+    dt_mean = sum(b[0] for b in blocks) / len(blocks)
+    tm_sum = _lib.SphTimings()
+    for _, tm in blocks:
+        for f in ("sort_ms", "neighbour_ms", "force_ms", "integrate_ms", "total_ms", "steps"):
+            setattr(tm_sum, f, getattr(tm_sum, f) + getattr(tm, f))
+    rest = report(dt_mean, tm_sum, args.steps, "settled" if args.settle else "rest")
+    first = report(blocks[0][0], blocks[0][1], args.steps, "rest")
+    dominant = rest["dominant"]
+    dk = rest["roofline_kernels"][dominant]
+    flop_per_particle = 2300.0 if "DENSITY" in dominant else 4600.0
+    dom_ms = dk["avg_launch_ms"]
     # VALU roofline of the same kernel.  Peak issue rate: 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction
     # (MI355X_MICROARCH.md; measured here 0.85-0.9 G wave-instructions/s per SIMD at the clock the chip sustains,
     # profiles/r02a_ubench_valu_table1.txt -- and half / a quarter of that for the 4- and 8-cycle opcode classes).
     # Useful work: SURVEY 8d's ~2.3 kFLOP (density) / ~4.6 kFLOP (force) per particle against 157.3 TFLOP/s.
-    VALU_PEAK_GINST = 1024 * 2.4 / 2.0
-    flop_per_particle = 2300.0 if "DENSITY" in dominant else 4600.0
     roofline_valu = {"kernel": dominant, "unit": "G wave-instructions/s", "peak": VALU_PEAK_GINST,
                      "peak_measured_full_rate_ops": round(1024 * 0.875, 1),
                      "useful_tflops": round(flop_per_particle * N / (dom_ms * 1e-3) / 1e12, 2) if dom_ms > 0 else None,
-                     "peak_tflops": 157.3, "achieved": None, "frac": None, "valu_wave_insts_per_launch": None,
-                     "insts_per_particle": None, "source": pmc_note}
+                     "peak_tflops": 157.3, "achieved": None, "frac": dk.get("valu_issue_frac"),
+                     "valu_wave_insts_per_launch": dk.get("valu_wave_insts"), "insts_per_particle": None, "source": pmc_note}
     if dom_ms > 0:
         roofline_valu["useful_frac_of_fp32_peak"] = round(roofline_valu["useful_tflops"] / 157.3, 4)
-    if pmc_k.get(dominant, {}).get("valu_wave_insts") and dom_ms > 0:
-        wi = pmc_k[dominant]["valu_wave_insts"]
-        roofline_valu.update(valu_wave_insts_per_launch=wi, achieved=round(wi / (dom_ms * 1e-3) / 1e9, 1),
-                             frac=round(wi / (dom_ms * 1e-3) / 1e9 / VALU_PEAK_GINST, 4),
-                             insts_per_particle=round(wi * 64 / N, 1))
+    if dk.get("valu_wave_insts") and dom_ms > 0:
+        roofline_valu.update(achieved=round(dk["valu_wave_insts"] / (dom_ms * 1e-3) / 1e9, 1),
+                             insts_per_particle=round(dk["valu_wave_insts"] * 64 / N, 1))
     line = {
         "metric": "WCSPH steps/sec at 1.74 M particles (+ ms/step breakdown sort/neighbour/force)",
-        "value": round(value, 3), "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": rest["value"], "unit": "steps/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": rest["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.workload, "particles": N, "cells": G, "dt": CFG["timeStepSize"],
                    "gather_impl": args.gather_impl, "brick_shape": args.brick_shape, "fused": args.fused,
-                   "kernel_variant": ps.get_option(_lib.OPT_KERNEL_VARIANT), "parallelism": "1 GPU"},
-        "breakdown_ms": {"sort": round(tm.sort_ms / k, 4), "neighbour": round(neigh_ms, 4),
-                         "force": round(force_ms, 4), "integrate": round(tm.integrate_ms / k, 4),
-                         "sum_of_phases": round(tm.total_ms / k, 4)},
-        "steps_per_s_job": round(steps_per_s, 3),
-        "roofline": {"kernel": dominant, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                     "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4),
-                     "valu_busy_frac": valu_busy, "counters": pmc_note,
+                   "kernel_variant": ps.get_option(_lib.OPT_KERNEL_VARIANT), "parallelism": "1 GPU",
+                   "settle_steps": args.settle, "state": "settled" if args.settle else "from rest (steps W..W+K of the initial lattice)"},
+        "reps": reps, "timed_seconds": round(t_timed, 3),
+        "first_rep": {"value": first["value"], "ms_per_step": first["ms_per_step"]},
+        "breakdown_ms": rest["breakdown_ms"],
+        "steps_per_s_job": round(args.steps / dt_mean, 3),
+        "roofline": {"kernel": dominant, "bound": "hbm", "achieved": dk["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": dk["frac_of_hbm_peak"], "traffic": dk["traffic"],
+                     "alg_bytes_per_launch": dk["alg_bytes"], "avg_launch_ms": dk["avg_launch_ms"],
+                     "counters": pmc_note,
                      "note": "fraction of the HBM roof on ALGORITHMIC bytes, as the contract asks; the sweep itself is "
                              "bound by VALU issue and the LDS / vector-memory pipes (roofline_valu, DESIGN.md section 4), "
                              "so this fraction measures how far the sweep is from a pure streaming pass, not HBM "
-                             "saturation; traffic = rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch"},
+                             "saturation; traffic = rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch; avg_launch_ms is the "
+                             "HIP-event time of the phase the kernel runs in (neighbour phase = brick-list kernel + sweep)"},
         "roofline_valu": roofline_valu,
-        "roofline_kernels": {k_: {"alg_bytes": v[0], "avg_launch_ms": round(v[1], 4),
-                                  "achieved_GBs": round(v[0] / (v[1] * 1e-3) / 1e9, 2) if v[1] > 0 else 0.0}
-                             for k_, v in kernels.items()},
+        "roofline_kernels": rest["roofline_kernels"],
+        "roofline_step": rest["roofline_step"],
+        "neighbourhood": dict(rest["neighbourhood"], note="last density sweep of the timed region (sph_get_stats); list entries = superset filter incl. self"),
     }
-    # secondary: whole-step algorithmic bytes (360 N + 20 G) against the same peak
-    step_bytes = 360.0 * N + 20.0 * G
-    line["roofline_step"] = {"alg_bytes": step_bytes, "achieved_GBs": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 2),
-                             "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
-    st = _lib.SphStats()
-    ps._call("sph_get_stats", st)
-    line["config"]["settle_steps"] = args.settle
-    line["neighbourhood"] = {
-        "mean_list_entries": round(st.list_entries / max(st.targets - st.list_overflow_targets - st.lds_overflow_targets, 1), 2),
-        "max_list_entries": st.max_list, "list_overflow_targets": st.list_overflow_targets,
-        "lds_overflow_targets": st.lds_overflow_targets, "max_cell_occupancy": st.max_cell_occupancy,
-        "mean_cell_occupancy": round(N / max(st.nonempty_cells, 1), 2),
-        "note": "last density sweep of the timed region (sph_get_stats); list entries = superset filter incl. self"}
+    # State B: the same box after `--settled-after` untimed steps (the fluid has sunk to its rest density: 10 particles
+    # per cell instead of the lattice's 8, 43 neighbours instead of 33) -- what a long run sees.  One contiguous block
+    # of at least K steps and at least --min-seconds.
+    if args.settle == 0 and args.settled_after > 0 and not args.ablate_mask:
+        ps.set_option(_lib.OPT_TIMING, 0)
+        solver.step(args.settled_after)
+        ps.sync()
+        dt_probe, _ = run(args.gather_impl, args.brick_shape, args.fused, args.steps, args.warmup)
+        n_set = max(args.steps, int(np.ceil(args.min_seconds / max(dt_probe / args.steps, 1e-9))))
+        n_set = min(n_set, args.steps * args.max_reps)
+        dt_s, tm_s = run(args.gather_impl, args.brick_shape, args.fused, n_set, 0)
+        settled = report(dt_s, tm_s, n_set, "settled")
+        settled.pop("dominant")
+        settled["after_steps"] = args.settled_after + 2 * args.warmup + args.steps
+        settled["timed_seconds"] = round(dt_s, 3)
+        line["settled"] = settled
     ps.close()
     if args.cpu_steps > 0:
         line["cpu_baseline"] = cpu_baseline(sd, args.cpu_steps)

@@ -917,10 +917,11 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
         for (int step = 16; step > 0; step >>= 1)
             if (sTOff[col_0 + step] <= tq) col_0 += step;
         gi_0 = sTG[col_0] + (tq - sTOff[col_0]);
-        Ai_0 = d.xm[gi_0];
+        // (the one-gather force sweep finds its targets' positions in the tile it stages: the stg record IS (x, y, z, U))
+        if (!(MODE == GM_FORCE_FUSED_U && !overflow)) Ai_0 = d.xm[gi_0];
         Bi_0 = d.vf[gi_0];
         Ei_0 = target_load_E<MODE>(d, gi_0);
-        key_0 = d.key[gi_0];
+        if (!mode_reads_list<MODE>()) key_0 = d.key[gi_0];  // (the cell's z layer: only the filter asks)
     }
 
     // SPH_VAR_RING: tag|base of every 32-candidate chunk of every target cell, in the order the filter walks them (nine
@@ -983,17 +984,25 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
             for (int step = 16; step > 0; step >>= 1)
                 if (sTOff[col + step] <= tq) col += step;
             gi = sTG[col] + (tq - sTOff[col]);
-            Ai = d.xm[gi];
+            if (!(MODE == GM_FORCE_FUSED_U && !overflow)) Ai = d.xm[gi];
             Bi = d.vf[gi];
             Ei = target_load_E<MODE>(d, gi);
-            key_i = d.key[gi];
+            if (!mode_reads_list<MODE>()) key_i = d.key[gi];
+        }
+        const int li = gi - sColG[col];  // own LDS slot
+        if (MODE == GM_FORCE_FUSED_U && !overflow) {
+            if (li >= sColS[col]) {
+                Ai = sQ[li];
+                Ai.w = Ai.w > 0.0f ? d.m_V0 : -Ai.w;  // U = m / rho_raw of a fluid particle (whose m_V is m_V0 on this path), -m_V of a solid one
+            } else {
+                Ai = d.xm[gi];  // a target in flat cell 0: its own range is never staged (the max(0, idx-1) quirk, step A)
+            }
         }
         Target t;
         target_init<MODE>(d, t, Ai, Bi, Ei);
         const bool g = target_gathers<MODE>(t.flags);
         bool walk = g && overflow;
         int cnt = 0;
-        const int li = gi - sColG[col];  // own LDS slot
         if (g && !overflow && !mode_reads_list<MODE>() && !(d.ablate & 4)) {
             const int ix = sx0 + col / ncy, iy = sy0 + col % ncy;
             const int cz = key_i - sph_flatten(d, ix, iy, 0);  // key = flatten(ix, iy, cz)

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SPH_ABI_VERSION 2
+#define SPH_ABI_VERSION 3
 
 typedef struct SphContext SphContext;
 
@@ -289,6 +289,39 @@ int32_t sph_sweeps(SphContext* ctx);
 int32_t sph_rigid_partial_sums(SphContext* ctx, int32_t object_id, int32_t first, int32_t count, double* dev_sums16);
 int32_t sph_rigid_apply_sums(SphContext* ctx, int32_t object_id, const double* dev_sums16, int32_t mode);
 int32_t sph_upload_rest_positions(SphContext* ctx, const int32_t* pid, const float* x0, int32_t n);
+
+/* ---- the slab exchange itself: RCCL point-to-point over xGMI, enqueued on the device (sph_comm.hip) ----
+ * SURVEY 8(b) sph_exchange_halo / sph_migrate.  One SphComm per context (= per GPU / rank).  The host gets the 128-byte
+ * RCCL unique id on rank 0 (sph_comm_unique_id), distributes it by whatever it has (torch.distributed, MPI, a file)
+ * and every rank calls sph_comm_create.  left / right below = the x-neighbours' ranks, -1 at a domain end (a rank may
+ * name itself: the loop-back used by the one-GPU tests).  librccl is dlopen'ed at the first call.
+ * Per step:  sph_slab_announce   after the sort, when the layer offsets -- hence the record counts of THIS step's
+ *                                messages -- are known: sends them ahead (non-blocking);
+ *            sph_slab_incoming   the counts the neighbours announced (waits for the tiny message: normally long there),
+ *                                so that the host can size its receive buffers;
+ *            sph_slab_exchange   ncclGroupStart; ncclSend / ncclRecv x <= 4; ncclGroupEnd on the communication stream,
+ *                                which first waits for the halo packers' event of sph_slab_forces (after_packers = 1;
+ *                                the interior force sweep keeps running on the main stream) or for the main stream
+ *                                (after_packers = 0); the main stream then waits for the exchange.  Nothing blocks the host.
+ * sph_comm_swap: fixed-size exchange (DFSPH ghost-velocity refresh); sph_comm_all_reduce: in-place sum of n doubles
+ * (dtype 0) or int64 (dtype 1) in device memory; both are ordered after the main stream's work and before what it
+ * does next.  sph_comm_halo_time: accumulated duration of the payload exchanges on the communication stream. */
+typedef struct SphComm SphComm;
+const char* sph_comm_last_error(void);
+int32_t sph_comm_unique_id(uint8_t* out128);
+int32_t sph_comm_create(SphContext* ctx, const uint8_t* id128, int32_t rank, int32_t world, SphComm** out);
+int32_t sph_comm_destroy(SphComm* comm);
+int32_t sph_slab_announce(SphContext* ctx, SphComm* comm, int32_t left, int32_t right, int32_t n_to_left, int32_t n_to_right);
+int32_t sph_slab_incoming(SphContext* ctx, SphComm* comm, int32_t* n_from_left, int32_t* n_from_right);
+int32_t sph_slab_exchange(SphContext* ctx, SphComm* comm, int32_t left, int32_t right, const void* send_left, int32_t n_to_left,
+                          const void* send_right, int32_t n_to_right, void* recv_left, int32_t n_from_left, void* recv_right,
+                          int32_t n_from_right, int32_t after_packers);
+int32_t sph_comm_swap(SphContext* ctx, SphComm* comm, int32_t left, int32_t right, const void* send_left, int64_t bytes_to_left,
+                      const void* send_right, int64_t bytes_to_right, void* recv_left, int64_t bytes_from_left, void* recv_right,
+                      int64_t bytes_from_right);
+int32_t sph_comm_all_reduce(SphContext* ctx, SphComm* comm, void* dev, int32_t n, int32_t dtype);
+int32_t sph_comm_sync(SphContext* ctx, SphComm* comm);
+int32_t sph_comm_halo_time(SphContext* ctx, SphComm* comm, double* ms, int64_t* exchanges);
 
 /* ======================================================================================
  * DFSPH (simulationMethod 4): DFSPHSolver of /root/reference/DFSPH.py on the same neighbour

@@ -59,7 +59,7 @@ OPT_GATHER_IMPL, OPT_TIMING, OPT_FUSED_STEP, OPT_BRICK_SHAPE, OPT_NO_DYNAMIC_SOL
     OPT_SLAB_DROP_OUTSIDE, OPT_UNIFORM_FLUID, OPT_UNIFORM_FLUID_STATE, OPT_SORT_BY_PID, OPT_KERNEL_VARIANT = range(11)
 VAR_PAD, VAR_2PHASE, VAR_MICRO, VAR_FORCE_BF, VAR_DEEP, VAR_MIRROR, VAR_SORTED, VAR_GROUPS, VAR_RING = 1, 2, 4, 8, 16, 32, 64, 128, 256
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # every symbol include/sph_hip.h declares: (name, restype, argtypes)
 _ctx = C.c_void_p
@@ -134,6 +134,19 @@ SYMBOLS = [
     ("sph_dfsph_step", C.c_int32, [_ctx, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
     ("sph_dfsph_compute_density_error_range", C.c_int32, [_ctx, C.c_float, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     ("sph_copy_velocity_records", C.c_int32, [_ctx, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
+    ("sph_comm_last_error", C.c_char_p, []),
+    ("sph_comm_unique_id", C.c_int32, [C.c_void_p]),
+    ("sph_comm_create", C.c_int32, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    ("sph_comm_destroy", C.c_int32, [C.c_void_p]),
+    ("sph_slab_announce", C.c_int32, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    ("sph_slab_incoming", C.c_int32, [_ctx, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("sph_slab_exchange", C.c_int32, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                      C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]),
+    ("sph_comm_swap", C.c_int32, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                  C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
+    ("sph_comm_all_reduce", C.c_int32, [_ctx, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
+    ("sph_comm_sync", C.c_int32, [_ctx, C.c_void_p]),
+    ("sph_comm_halo_time", C.c_int32, [_ctx, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 ]
 
 _LIB = None

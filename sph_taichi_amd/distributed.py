@@ -55,6 +55,7 @@ from __future__ import annotations
 
 import copy
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -210,6 +211,128 @@ class TorchTransport:
         if self.torch.cuda.is_available() and t.is_cuda:
             self.torch.cuda.current_stream().synchronize()   # consumed on the context's stream
         return t
+
+
+class NativeTransport:
+    """The exchange behind the C ABI (csrc/sph_comm.hip): RCCL send / recv enqueued on the context's communication
+    stream right behind the halo packers, the next step's counts announced after the sort -- the host never waits for
+    the GPU inside a step.  torch.distributed (any backend) is used ONCE, to hand rank 0's 128-byte RCCL unique id to
+    the other ranks; `unique_id` (bytes) skips even that (MPI, a shared file, ...).  Same interface as TorchTransport;
+    `stream_ordered` tells SlabSolver not to block on the packers' event before calling exchange()."""
+
+    stream_ordered = True
+
+    def __init__(self, ps, device, rank=None, world=None, unique_id=None, loopback=False):
+        import torch
+        self.torch = torch
+        self.ps, self.lib, self.ctx = ps, ps._lib, ps._ctx
+        self.device = device
+        self.loopback = bool(loopback)
+        if rank is None or world is None:
+            import torch.distributed as dist
+            rank, world = dist.get_rank(), dist.get_world_size()
+        self.rank, self.world = int(rank), int(world)
+        if unique_id is None:
+            uid = (C.c_uint8 * 128)()
+            if self.rank == 0:
+                rc = self.lib.sph_comm_unique_id(uid)
+                if rc:
+                    raise _lib.SphError(f"sph_comm_unique_id: {self.lib.sph_comm_last_error().decode()}")
+            if self.world > 1:
+                import torch.distributed as dist
+                on_dev = dist.get_backend() == "nccl"
+                t = torch.tensor(list(uid), dtype=torch.uint8, device=device if on_dev else "cpu")
+                dist.broadcast(t, 0)
+                uid = (C.c_uint8 * 128)(*t.cpu().tolist())
+        else:
+            uid = (C.c_uint8 * 128)(*bytes(unique_id))
+        comm = C.c_void_p()
+        rc = self.lib.sph_comm_create(self.ctx, uid, self.rank, self.world, C.byref(comm))
+        _lib.check(self.lib, self.ctx, rc, "sph_comm_create")
+        self.comm = comm
+        self._announced = None
+        self._incoming = None
+
+    def close(self):
+        if getattr(self, "comm", None):
+            self.lib.sph_comm_destroy(self.comm)
+            self.comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _neighbours(self):
+        if self.loopback:
+            return self.rank, -1
+        return (self.rank - 1 if self.rank > 0 else -1), (self.rank + 1 if self.rank < self.world - 1 else -1)
+
+    def _call(self, name, *args):
+        rc = getattr(self.lib, name)(self.ctx, self.comm, *args)
+        _lib.check(self.lib, self.ctx, rc, name)
+
+    @staticmethod
+    def _ptr(t):
+        return C.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else None
+
+    def start_counts(self, n_left, n_right):
+        left, right = self._neighbours()
+        self._call("sph_slab_announce", left, right, int(n_left) if left >= 0 else 0, int(n_right) if right >= 0 else 0)
+        self._announced = (int(n_left), int(n_right))
+        self._incoming = None
+
+    def resolve_counts(self):
+        if self._announced is None or self._incoming is not None:
+            return
+        a, b = C.c_int32(), C.c_int32()
+        self._call("sph_slab_incoming", C.byref(a), C.byref(b))
+        self._incoming = (int(a.value), int(b.value))
+
+    def exchange(self, send_left, n_left, send_right, n_right, alloc, after_packers=False):
+        left, right = self._neighbours()
+        if self._announced is None:
+            self.start_counts(n_left, n_right)
+        if self._announced != (int(n_left), int(n_right)):
+            raise RuntimeError(f"rank {self.rank}: announced counts {self._announced} != sent counts {(n_left, n_right)}")
+        self.resolve_counts()
+        in_l, in_r = self._incoming
+        in_l = in_l if left >= 0 else 0
+        in_r = in_r if right >= 0 else 0
+        rl = alloc(True, in_l) if in_l > 0 else None
+        rr = alloc(False, in_r) if in_r > 0 else None
+        self._call("sph_slab_exchange", left, right,
+                   self._ptr(send_left) if left >= 0 and n_left > 0 else None, int(n_left) if left >= 0 else 0,
+                   self._ptr(send_right) if right >= 0 and n_right > 0 else None, int(n_right) if right >= 0 else 0,
+                   self._ptr(rl), in_l, self._ptr(rr), in_r, 1 if after_packers else 0)
+        self._announced = None
+        self._incoming = None
+        return rl, in_l, rr, in_r
+
+    def swap(self, send_left, send_right, recv_left, recv_right):
+        left, right = self._neighbours()
+        nb = lambda t, ok: int(t.numel() * t.element_size()) if (ok and t is not None) else 0
+        self._call("sph_comm_swap", left, right,
+                   self._ptr(send_left) if left >= 0 else None, nb(send_left, left >= 0),
+                   self._ptr(send_right) if right >= 0 else None, nb(send_right, right >= 0),
+                   self._ptr(recv_left) if left >= 0 else None, nb(recv_left, left >= 0),
+                   self._ptr(recv_right) if right >= 0 else None, nb(recv_right, right >= 0))
+
+    def all_reduce_sum(self, t):
+        """In-place sum over ranks of a small device tensor (float64 or int64); returns after it is complete."""
+        torch = self.torch
+        if t.dtype not in (torch.float64, torch.int64) or not t.is_cuda:
+            raise TypeError("NativeTransport.all_reduce_sum: float64 / int64 device tensors only")
+        torch.cuda.current_stream(t.device).synchronize()      # the tensor was filled on torch's stream
+        self._call("sph_comm_all_reduce", C.c_void_p(t.data_ptr()), int(t.numel()), 0 if t.dtype == torch.float64 else 1)
+        self.ps.sync()                                         # (the main stream waits for the communication stream)
+        return t
+
+    def halo_time(self):
+        ms, n = C.c_double(), C.c_int64()
+        self._call("sph_comm_halo_time", C.byref(ms), C.byref(n))
+        return float(ms.value), int(n.value)
 
 
 def plan_recut(cuts, hist, world, halo, width_cap=None):
@@ -414,7 +537,9 @@ class SlabSolver:
                  fR, nR, C.c_void_p(self.send_buf["R"].data_ptr()))
         if getattr(self, "transport", None) is not None and hasattr(self.transport, "resolve_counts"):
             self.transport.resolve_counts()        # the neighbours' counts, read while the packers are still queued
-        ps._call("sph_slab_wait_pack")
+        self._packers_pending = pack and bool(getattr(getattr(self, "transport", None), "stream_ordered", False))
+        if not self._packers_pending:
+            ps._call("sph_slab_wait_pack")
         self.stats["sent"] += nL + nR
         return self.send_buf["L"], nL, self.send_buf["R"], nR
 
@@ -422,6 +547,7 @@ class SlabSolver:
         """Pack the boundary layers as they are now (after advect + rigid solve); synchronises."""
         fL, nL, fR, nR = self.pack_ranges()
         self._ensure_send_bufs(nL, nR)
+        self._packers_pending = False
         self.ps._call("sph_slab_pack", fL, nL, C.c_void_p(self.send_buf["L"].data_ptr()),
                       fR, nR, C.c_void_p(self.send_buf["R"].data_ptr()))
         self.stats["sent"] += nL + nR
@@ -542,8 +668,13 @@ class SlabSolver:
         self.transport = transport
 
     def _exchange(self, sL, nL, sR, nR):
-        return self.transport.exchange(sL if self.has_left else None, nL, sR if self.has_right else None, nR,
-                                       self._alloc_recv)
+        tr = self.transport
+        if getattr(tr, "stream_ordered", False):
+            # the exchange is enqueued behind the packers' event on the device: nobody waited for them on the host
+            pending, self._packers_pending = getattr(self, "_packers_pending", False), False
+            return tr.exchange(sL if self.has_left else None, nL, sR if self.has_right else None, nR, self._alloc_recv,
+                               after_packers=pending)
+        return tr.exchange(sL if self.has_left else None, nL, sR if self.has_right else None, nR, self._alloc_recv)
 
     # -- DFSPH across slabs -----------------------------------------------------------------------------
     def velocity_band(self, side):
@@ -845,7 +976,15 @@ def run_slab_bench(args, rank, world, local_rank):
         sd["Configuration"]["timeStepSize"] = 0.004
     s = SlabSolver(sd, rank, world, device=local_rank, gather_impl=args.gather_impl, brick_shape=args.brick_shape,
                    recut_every=getattr(args, "recut_every", 0))
-    s.attach(TorchTransport(torch.device("cuda", local_rank)))
+    # The exchange: RCCL behind the C ABI (NativeTransport: enqueued on the device, no host wait inside a step) when
+    # the job runs on RCCL; torch.distributed P2P otherwise (gloo: several ranks sharing one GPU) or on request
+    # (SPH_TRANSPORT=torch).
+    want = os.environ.get("SPH_TRANSPORT", "native" if dist.get_backend() == "nccl" else "torch")
+    if want == "native":
+        transport = NativeTransport(s.ps, torch.device("cuda", local_rank))
+    else:
+        transport = TorchTransport(torch.device("cuda", local_rank))
+    s.attach(transport)
     s.initialize()
     s.step(args.warmup)
     s.ps.sync()
@@ -903,7 +1042,7 @@ def run_slab_bench(args, rank, world, local_rank):
         "config": {"workload": f"c3p_tiled_x{world}_{246 * world}x74x96", "particles": n_global,
                    "particles_owned_sum": int(own.item()), "cuts": s.cuts, "halo_layers": s.halo,
                    "sent_records_per_step": round(s.stats["sent"] / max(args.steps + args.warmup + 1, 1), 1),
-                   "backend": dist.get_backend(), "recut_every": s.recut_every,
+                   "backend": dist.get_backend(), "transport": type(transport).__name__, "recut_every": s.recut_every,
                    "rank0_host_ms_per_step": {k: round(v / max(host_ms["steps"], 1), 4)
                                               for k, v in host_ms.items() if k != "steps"},
                    "parallelism": f"x-slab x{world}, 1 exchange/step over "
@@ -923,5 +1062,11 @@ def run_slab_bench(args, rank, world, local_rank):
     if dfsph:
         line["config"]["solver"] = "dfsph"
         line["config"]["last_step_iterations"] = list(getattr(s, "dfsph_iterations", (0, 0)))
+    if isinstance(transport, NativeTransport):
+        ms, n = transport.halo_time()
+        line["breakdown_ms"]["halo_device"] = round(ms / max(n, 1), 4)
+        line["breakdown_ms"]["note"] += ("; halo_device: mean duration of the payload exchange on rank 0's communication "
+                                         "stream (HIP events around ncclGroupStart..End)")
+        transport.close()
     s.close()
     return line

@@ -23,14 +23,57 @@ def main():
     mode, rank, world, port, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     import torch
     import torch.distributed as dist
-    if mode == "rccl1":
+    if mode in ("rccl1", "native1"):
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
                                 device_id=torch.device("cuda", 0))
     else:
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    from sph_taichi_amd.distributed import TorchTransport, SlabSolver, RECORD_BYTES
-    if mode == "rccl1":
+    from sph_taichi_amd.distributed import TorchTransport, NativeTransport, SlabSolver, RECORD_BYTES
+    if mode == "native1":
+        # The exchange behind the C ABI (csrc/sph_comm.hip) on the hardware there is: ONE rank, its own left neighbour.
+        import json
+        dev = torch.device("cuda", 0)
+        sd = json.load(open(sys.argv[6]))
+        steps = int(sys.argv[7])
+        s = SlabSolver(sd, 0, 1, device=0, recut_every=2, check_every=3)
+        tr = NativeTransport(s.ps, dev, loopback=True)
+        ok = True
+        for it in range(5):                  # ragged payloads, sometimes empty; counts announced one round ahead
+            n = (3 + 2 * it) % 5
+            payload = (torch.arange(max(n, 1) * RECORD_BYTES, device=dev) % 251 + it).to(torch.uint8)
+            torch.cuda.synchronize()
+            alloc = lambda from_left, m: torch.zeros(m * RECORD_BYTES, dtype=torch.uint8, device=dev)
+            rL, mL, rR, mR = tr.exchange(payload, n, None, 0, alloc)
+            s.ps.sync()
+            ok &= mL == n and mR == 0 and (n == 0 or bool(torch.equal(rL[: n * RECORD_BYTES], payload[: n * RECORD_BYTES])))
+            if it < 4:
+                tr.start_counts((3 + 2 * (it + 1)) % 5, 0)
+        a = torch.arange(4096, device=dev, dtype=torch.int32).view(torch.uint8)     # DFSPH ghost-velocity refresh path
+        b = torch.zeros_like(a)
+        torch.cuda.synchronize()
+        tr.swap(a, None, b, None)
+        s.ps.sync()
+        ok &= bool(torch.equal(a, b))
+        t = torch.arange(16, dtype=torch.float64, device=dev) * 3.0               # the bodies' 16 shape-matching sums
+        tr.all_reduce_sum(t)
+        ok &= bool(torch.equal(t.cpu(), torch.arange(16, dtype=torch.float64) * 3.0))
+        ti = torch.tensor([41], dtype=torch.int64, device=dev)                      # the conservation guard's count
+        ok &= int(tr.all_reduce_sum(ti).item()) == 41
+        ms, nx = tr.halo_time()
+        ok &= nx == 5 and ms >= 0.0
+        tr.close()
+        tr2 = NativeTransport(s.ps, dev)          # a second communicator: the solver's own (world 1, no neighbours)
+        s.attach(tr2)
+        s.initialize()
+        s.step(steps)
+        ok &= s.stats.get("recuts", 0) == 0
+        o = s.owned(("pid", "x", "v", "density"))
+        np.savez(out, ok=np.int32(1 if ok else 0), pid=o["pid"], x=o["x"], v=o["v"], density=o["density"],
+                 backend=np.array("native-rccl"))
+        tr2.close()
+        s.close()
+    elif mode == "rccl1":
         import json
         dev = torch.device("cuda", 0)
         assert dist.get_backend() == "nccl"

@@ -365,6 +365,36 @@ def test_rccl_one_rank_transport_and_slab_solver(tmp_path):
 
 
 @pytest.mark.gpu
+def test_native_rccl_exchange_behind_the_c_abi(tmp_path):
+    """SURVEY 8(b) sph_exchange_halo / sph_migrate as C entry points (csrc/sph_comm.hip): communicator from a unique id,
+    counts announced ahead, ncclSend / ncclRecv groups enqueued on the communication stream, fixed-size swap, f64 and
+    i64 all-reduce -- executed with ONE rank as its own neighbour (the hardware there is), then a SlabSolver with
+    shape-matched bodies, re-cut events and the conservation guard running over NativeTransport, against the single
+    domain."""
+    sd = scenes.fluid_with_rigid_bodies(str(tmp_path / "cube.obj"))
+    steps = 12
+    ref, n = _single_domain(sd, steps)
+    scene_file = str(tmp_path / "scene.json")
+    json.dump(sd, open(scene_file, "w"))
+    out = str(tmp_path / "res.npz")
+    port = _free_port()
+    p = subprocess.Popen([sys.executable, os.path.join(HERE, "slab_worker.py"), "native1", "0", "1", str(port), out,
+                          scene_file, str(steps)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    try:
+        log = p.communicate(timeout=240)[0].decode()
+    except subprocess.TimeoutExpired:
+        p.kill()
+        raise AssertionError("native RCCL worker hung:\n" + p.communicate()[0].decode()[-3000:])
+    assert p.returncode == 0, log[-3000:]
+    z = np.load(out)
+    assert str(z["backend"]) == "native-rccl" and int(z["ok"]) == 1, log[-2000:]
+    assert np.array_equal(np.sort(z["pid"]), np.arange(n))
+    x = np.empty_like(ref["x"])
+    x[z["pid"]] = z["x"]
+    assert scenes.rel_l2(x, ref["x"]) <= 2e-6
+
+
+@pytest.mark.gpu
 def test_conservation_guard_raises_when_a_particle_outruns_the_halo():
     """a particle that crosses more than one cell layer in a step is dropped (or duplicated) by the
     exchange; the guard must turn that into an error instead of a silently different fluid."""

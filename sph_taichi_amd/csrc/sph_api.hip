@@ -43,13 +43,14 @@ DevView sph_view(const SphContext* c) {
     }
     const int o = c->in_off;
     d.xm = c->xm[c->cur] + o; d.vf = c->vf[c->cur] + o; d.aux = c->aux[c->cur] + o; d.key = c->key[c->cur] + o;
-    d.eos = c->eos; d.eos2 = reinterpret_cast<float2*>(c->eos); d.acc = c->acc + o; d.cell_end = c->cell_end;
+    d.eos = c->eos; d.eos2 = reinterpret_cast<float2*>(c->eos); d.acc = c->acc + o; d.acc_fx = c->acc_fx + 3 * (size_t)o; d.cell_end = c->cell_end;
     d.x0_cold = c->x0_cold; d.rigid_rest_cm = c->rigid_rest_cm;
     d.m_eps = c->df.m_eps;
     d.stg = c->stg; d.gat = c->gat; d.kbuf = reinterpret_cast<float*>(c->gat);
     d.m_u = c->m_uniform; d.write_sg = 0; d.write_k = 0;
     d.whx = p.wall_hi[0]; d.why = p.wall_hi[1]; d.whz = p.wall_hi[2];
     d.fuse_advect = c->fuse_advect;
+    d.fx_scale = ldexp(1.0, c->rigid_fx_exp);
     d.store_acc = !(c->fuse_advect && c->skip_acc);
     return d;
 }
@@ -145,6 +146,7 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     rc = rc ? rc : alloc_dev(c, (void**)&c->gat, cap * 16);
     rc = rc ? rc : alloc_dev(c, (void**)&c->acc, cap * 16);
     rc = rc ? rc : alloc_dev(c, (void**)&c->acc_tmp, cap * 16);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->acc_fx, cap * 3 * sizeof(long long));  // all zero except between a coupling sweep and its fold
     rc = rc ? rc : alloc_dev(c, (void**)&c->cell_buf[0], (size_t)c->scan_blocks * SCAN_TILE * 4);
     rc = rc ? rc : alloc_dev(c, (void**)&c->cell_buf[1], (size_t)c->scan_blocks * SCAN_TILE * 4);
     if (!rc) { c->cell_cur = 0; c->cell_end = c->cell_buf[0]; c->next_cells_zero = false; }
@@ -191,6 +193,7 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
         return rc;
     }
     c->n_dyn_host = -1;  // unknown until material / is_dynamic are uploaded
+    c->rigid_fx_exp = 30;
     sph_invalidate_lists(c);
     c->opt_uniform = -1; c->uniform_state = -1; c->m_uniform = 0.0f;  // SPH_OPT_UNIFORM_FLUID: auto
     c->opt_variant = SPH_VAR_DEFAULT;
@@ -208,7 +211,7 @@ int32_t sph_destroy(SphContext* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->xm[0], c->xm[1], c->vf[0], c->vf[1], c->aux[0], c->aux[1], c->key[0], c->key[1], c->eos, c->stg, c->gat, c->acc,
                     c->acc_tmp, c->cell_buf[0], c->cell_buf[1], c->rank_off, c->idx_unstable, c->scan_sums, c->x0_cold, c->color_cold,
-                    c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->rigid_part, c->rigid_R, c->df_err, c->df_part, c->stage, c->glist, c->gcnt, c->brick_list, c->brick_count, c->brick_list2, c->brick_count2};
+                    c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->acc_fx, c->rigid_part, c->rigid_R, c->df_err, c->df_part, c->stage, c->glist, c->gcnt, c->brick_list, c->brick_count, c->brick_list2, c->brick_count2};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < SPH_MAX_TIMED_STEPS; ++s)
         for (int k = 0; k < 5; ++k) if (c->ev[s][k]) (void)hipEventDestroy(c->ev[s][k]);
@@ -316,7 +319,7 @@ int32_t sph_upload(SphContext* c, int32_t field, const void* host, size_t bytes)
     int rc = sphk_insert(c, field, c->stage);
     if (rc) return rc;
     SPH_HIP(c, hipStreamSynchronize(c->stream));  // host buffer is only borrowed for the call
-    if (field == SPH_F_MATERIAL || field == SPH_F_IS_DYNAMIC) c->n_dyn_host = -1;
+    if (field == SPH_F_MATERIAL || field == SPH_F_IS_DYNAMIC || field == SPH_F_DENSITY) c->n_dyn_host = -1;  // (density: the scale of the rigid sums)
     if (field == SPH_F_MATERIAL || field == SPH_F_M || field == SPH_F_M_V) c->uniform_state = -1;
     if (field == SPH_F_X) c->have_keys = c->have_prefix = false;
     return 0;
@@ -347,10 +350,22 @@ static int refresh_dyn(SphContext* c) {
     if (c->opt_no_dynamic) { c->n_dyn_host = 0; return 0; }  // the host vouches: no dynamic solids anywhere
     int rc = sphk_build_dyn_list(c);
     if (rc) return rc;
-    int n = 0;
-    SPH_HIP(c, hipMemcpyAsync(&n, c->dyn_count, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    int nr[2] = {0, 0};
+    SPH_HIP(c, hipMemcpyAsync(nr, c->dyn_count, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     SPH_HIP(c, hipStreamSynchronize(c->stream));
-    c->n_dyn_host = n;
+    c->n_dyn_host = nr[0];
+    // Scale of the fixed-point shape-matching sums: n terms of at most m_V0 rho_max L^2 (L = twice the domain's largest
+    // extent, a generous bound for |x|, |x - cm| and |x_0 - cm_rest|) must stay below 2^62.
+    float rho_max;
+    memcpy(&rho_max, &nr[1], sizeof(float));
+    double L = 1.0;
+    for (int a = 0; a < 3; ++a) L = fmax(L, 2.0 * fabs((double)c->p.domain_size[a]) + 1.0);
+    const double bound = fmax((double)nr[0], 1.0) * fmax((double)c->p.m_V0 * fmax((double)rho_max, 1.0), 1e-30) * L * L;
+    int e = 0;
+    (void)frexp(bound, &e);          // bound < 2^e
+    c->rigid_fx_exp = 62 - e;
+    if (c->rigid_fx_exp > 80) c->rigid_fx_exp = 80;
+    if (c->rigid_fx_exp < -200) c->rigid_fx_exp = -200;
     return 0;
 }
 
@@ -840,6 +855,10 @@ int32_t sph_slab_forces(SphContext* c, int32_t bl_lo, int32_t bl_hi, int32_t br_
         c->use_side = true;
     }
     rc = sphk_gather_layers(c, GM_FORCE_FUSED, f_lo, bl_hi, br_lo, f_hi);
+    // the packed layers' dynamic solids: their coupling reactions all come from the boundary sets (which reach one
+    // layer further in for that), so they are complete now and the packers can advance them
+    rc = rc ? rc : sphk_fold_coupling_range(c, firstL, nL);
+    rc = rc ? rc : sphk_fold_coupling_range(c, firstR, nR);
     rc = rc ? rc : sphk_pack_advected(c, firstL, nL, dstL);
     rc = rc ? rc : sphk_pack_advected(c, firstR, nR, dstR);
     c->use_side = false;
@@ -856,6 +875,7 @@ int32_t sph_slab_forces(SphContext* c, int32_t bl_lo, int32_t bl_hi, int32_t br_
     if (!no_boundary) SPH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pack, 0));  // the packers read what the advect overwrites
     hipEvent_t* ev = c->slab_ev_open ? c->ev[c->ev_used] : nullptr;
     if (ev) SPH_HIP(c, hipEventRecord(ev[3], c->stream));  // force = interior sweep (+ the wait for the side stream)
+    if (c->n_dyn_host != 0) { rc = sphk_fold_coupling(c); if (rc) return rc; }  // both force launches have joined: reactions -> accelerations
     if (fuse) {
         // (in a slab only HALO+1 layers wide the two packed ranges overlap: advect their union once)
         const int a0 = firstL, a1 = firstL + nL, b0 = firstR, b1 = firstR + nR;

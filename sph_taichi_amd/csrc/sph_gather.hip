@@ -186,6 +186,19 @@ __device__ __forceinline__ bool sph_within(const DevView& d, float r2, float rn)
     return in;
 }
 
+// Two-way coupling (WCSPH.py:66-68, DFSPH.py:313, 389-390): the reaction on a dynamic rigid particle is collected
+// from many fluid lanes of many workgroups.  f32 atomic adds would make the sum depend on the order the hardware
+// happens to serve them in; here every contribution is rounded once to 2^-32 fixed point and added as a 64-bit
+// integer -- associative, hence bit-reproducible -- and k_fold_coupling adds the total to the particle's
+// acceleration after the sweep (range +-2^31 m/s^2, resolution 2.3e-10: far below an f32 ulp of any acceleration
+// that matters).
+__device__ __forceinline__ void couple_scatter(const DevView& d, int gj, float fx, float fy, float fz) {
+    unsigned long long* a = reinterpret_cast<unsigned long long*>(d.acc_fx) + 3 * (size_t)gj;
+    atomicAdd(a + 0, (unsigned long long)__float2ll_rn(fx * 4294967296.0f));
+    atomicAdd(a + 1, (unsigned long long)__float2ll_rn(fy * 4294967296.0f));
+    atomicAdd(a + 2, (unsigned long long)__float2ll_rn(fz * 4294967296.0f));
+}
+
 // One accepted pair (i != j, r_norm = |x_i - x_j| < h).  gj = global (sorted)
 // index of j, needed only for the coupling scatter.
 template <int MODE>
@@ -223,10 +236,7 @@ __device__ __forceinline__ void pair_physics(const DevView& d, Target& t, float 
             t.px += fx; t.py += fy; t.pz += fz;
             if (B.w != 0.0f) {
                 const float sc = d.rho0 * sph_rcp(d.aux[gj].y);  // density[p_j] of the body particle
-                float* a = reinterpret_cast<float*>(&d.acc[gj]);
-                unsafeAtomicAdd(a + 0, -fx * sc);
-                unsafeAtomicAdd(a + 1, -fy * sc);
-                unsafeAtomicAdd(a + 2, -fz * sc);
+                couple_scatter(d, gj, -fx * sc, -fy * sc, -fz * sc);
             }
         }
         return;
@@ -259,10 +269,7 @@ __device__ __forceinline__ void pair_physics(const DevView& d, Target& t, float 
             t.ax += fx; t.ay += fy; t.az += fz;
             if (sph_is_dynamic_rigid(__float_as_int(d.vf[gj].w))) {  // solid neighbours are few: fetched only here
                 const float sc = t.rho * sph_rcp(d.eos[gj].w) * sph_rcp(d.dt);
-                float* a = reinterpret_cast<float*>(&d.acc[gj]);
-                unsafeAtomicAdd(a + 0, -fx * sc);
-                unsafeAtomicAdd(a + 1, -fy * sc);
-                unsafeAtomicAdd(a + 2, -fz * sc);
+                couple_scatter(d, gj, -fx * sc, -fy * sc, -fz * sc);
             }
         }
         return;
@@ -281,10 +288,7 @@ __device__ __forceinline__ void pair_physics(const DevView& d, Target& t, float 
             t.ax += fx; t.ay += fy; t.az += fz;
             if (sph_is_dynamic_rigid(fj)) {  // DFSPH.py:313 / :389-390: -vel_change / dt * rho_i / rho_j
                 const float sc = t.rho * sph_rcp(Cc.w) * sph_rcp(d.dt);
-                float* a = reinterpret_cast<float*>(&d.acc[gj]);
-                unsafeAtomicAdd(a + 0, -fx * sc);
-                unsafeAtomicAdd(a + 1, -fy * sc);
-                unsafeAtomicAdd(a + 2, -fz * sc);
+                couple_scatter(d, gj, -fx * sc, -fy * sc, -fz * sc);
             }
         }
         return;
@@ -325,10 +329,7 @@ __device__ __forceinline__ void pair_physics(const DevView& d, Target& t, float 
             t.px += fx; t.py += fy; t.pz += fz;
             if (sph_is_dynamic_rigid(fj)) {
                 const float sc = d.rho0 * sph_rcp(Cc.w);
-                float* a = reinterpret_cast<float*>(&d.acc[gj]);
-                unsafeAtomicAdd(a + 0, -fx * sc);
-                unsafeAtomicAdd(a + 1, -fy * sc);
-                unsafeAtomicAdd(a + 2, -fz * sc);
+                couple_scatter(d, gj, -fx * sc, -fy * sc, -fz * sc);
             }
         }
     }
@@ -366,10 +367,7 @@ __device__ __forceinline__ void pair_force_u_bf(const DevView& d, Target& t, flo
         t.px += fx; t.py += fy; t.pz += fz;
         if (B.w != 0.0f) {
             const float sc = d.rho0 * sph_rcp(d.aux[gj].y);  // density[p_j] of the body particle
-            float* a = reinterpret_cast<float*>(&d.acc[gj]);
-            unsafeAtomicAdd(a + 0, -fx * sc);
-            unsafeAtomicAdd(a + 1, -fy * sc);
-            unsafeAtomicAdd(a + 2, -fz * sc);
+            couple_scatter(d, gj, -fx * sc, -fy * sc, -fz * sc);
         }
     }
 }
@@ -1423,6 +1421,47 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
     }
 }
 
+// after a sweep that scatters coupling reactions: acc of every dynamic rigid particle += its fixed-point sums, which
+// return to zero (the accumulators are all zero between sweeps, whatever the order of the particles becomes)
+__global__ __launch_bounds__(TPB) void k_fold_coupling(DevView d, const int* __restrict__ list, int first, int n) {
+    const int t = blockIdx.x * TPB + threadIdx.x;
+    if (t >= n) return;
+    // list == nullptr: the list of dynamic rigid particles is not current (a slab rank between its truncate and the
+    // next sort): every particle looks at its own flags instead
+    const int i = list ? list[t] : first + t;
+    if (!list && !sph_is_dynamic_rigid(__float_as_int(d.vf[i].w))) return;
+    long long* f = d.acc_fx + 3 * (size_t)i;
+    const long long fx = f[0], fy = f[1], fz = f[2];
+    if ((fx | fy | fz) == 0) return;
+    f[0] = 0; f[1] = 0; f[2] = 0;
+    float4 a = d.acc[i];
+    a.x += (float)((double)fx * (1.0 / 4294967296.0));
+    a.y += (float)((double)fy * (1.0 / 4294967296.0));
+    a.z += (float)((double)fz * (1.0 / 4294967296.0));
+    d.acc[i] = a;
+}
+
+int sphk_fold_coupling(SphContext* c) {
+    if (c->opt_no_dynamic || c->n_dyn_host == 0 || c->N <= 0) return 0;
+    DevView d = sph_view(c);
+    const bool have_list = c->n_dyn_host > 0;
+    const int n = have_list ? c->n_dyn_host : c->N;
+    hipLaunchKernelGGL(k_fold_coupling, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, have_list ? c->dyn_list : nullptr, 0, n);
+    SPH_LAUNCH_CHECK(c);
+    return 0;
+}
+
+// the same for the records [first, first + count) only, on the stream the sweeps of the moment run on (slab mode:
+// the halo packers advance the boundary layers' records right behind the boundary force launch and need those
+// particles' reactions -- complete by then, sph_slab_forces -- while the interior launch is still scattering to others)
+int sphk_fold_coupling_range(SphContext* c, int first, int count) {
+    if (c->opt_no_dynamic || c->n_dyn_host == 0 || count <= 0) return 0;
+    DevView d = sph_view(c);
+    hipLaunchKernelGGL(k_fold_coupling, dim3((count + TPB - 1) / TPB), dim3(TPB), 0, sph_stream(c), d, (const int*)nullptr, first, count);
+    SPH_LAUNCH_CHECK(c);
+    return 0;
+}
+
 // density / pressure of the fluid from the lean record (p, rho) of the uniform-fluid step into aux (sph_ensure_aux)
 __global__ __launch_bounds__(TPB) void k_aux_from_eos2(DevView d) {
     const int i = blockIdx.x * TPB + threadIdx.x;
@@ -1612,7 +1651,17 @@ static int launch_df(SphContext* c) {
     return rc;
 }
 
+static int gather_dispatch(SphContext* c, int mode);
+
 int sphk_gather(SphContext* c, int mode) {
+    int rc = gather_dispatch(c, mode);
+    // sweeps that scatter two-way coupling reactions (WCSPH.py:66-68, DFSPH.py:313, 389-390) are followed by the fold
+    if (!rc && c->n_dyn_host != 0 && (mode == GM_PRESSURE || mode == GM_FORCE_FUSED || mode == GM_DF_DIV_ITER || mode == GM_DF_PRESSURE_ITER))
+        rc = sphk_fold_coupling(c);
+    return rc;
+}
+
+static int gather_dispatch(SphContext* c, int mode) {
     // every sweep but the fused step's own pair reads or rewrites density / pressure in aux
     if (c->aux_stale && mode != GM_DENSITY_EOS && mode != GM_FORCE_FUSED && mode != GM_BVOL_STATIC && mode != GM_BVOL_DYNAMIC) {
         int rc = sph_ensure_aux(c);

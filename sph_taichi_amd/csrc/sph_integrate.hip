@@ -179,7 +179,15 @@ __global__ __launch_bounds__(TPB) void k_enforce_boundary(DevView d, WallHi hi, 
 // part[block][16] ([0] = sum m, [1..3] = sum m x, [4..12] = A row-major); consumers add the partials up in block
 // order.  No atomics, so the result does not depend on scheduling (the reference's f32 atomic sums do).
 #define RIGID_PART 16
-__device__ __forceinline__ double wave_sum(double v) {
+// The sums are EXACT and therefore independent of the order in which the list of dynamic-rigid particles happens to
+// be filled (the scatter appends to it with an atomic): every term is rounded once to 64-bit fixed point
+// (d.fx_scale = 2^S, S chosen on the host from the number of dynamic particles, their largest density and the domain
+// size so that the sum cannot overflow) and integers add associatively.  cm and R are then bit-reproducible from run
+// to run, which a checkpoint restart with dynamic bodies needs (the reference's serial run is deterministic too,
+// sph_base.py:200-222).
+typedef long long fx_t;
+__device__ __forceinline__ fx_t to_fx(const DevView& d, double v) { return __double2ll_rn(v * d.fx_scale); }
+__device__ __forceinline__ fx_t wave_sum(fx_t v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
@@ -187,17 +195,17 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // block-wide sum of NV values per thread -> part[blockIdx][off + k]
 template <int NV>
-__device__ __forceinline__ void block_store_partials(const double (&s)[NV], double* __restrict__ part, int off) {
-    __shared__ double red[TPB / 64][NV];
+__device__ __forceinline__ void block_store_partials(const fx_t (&s)[NV], fx_t* __restrict__ part, int off) {
+    __shared__ fx_t red[TPB / 64][NV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
-        const double w = wave_sum(s[k]);
+        const fx_t w = wave_sum(s[k]);
         if (lane == 0) red[wave][k] = w;
     }
     __syncthreads();
     if (threadIdx.x < NV) {
-        double t = 0.0;
+        fx_t t = 0;
 #pragma unroll
         for (int w = 0; w < TPB / 64; ++w) t += red[w][threadIdx.x];
         part[(size_t)blockIdx.x * RIGID_PART + off + threadIdx.x] = t;
@@ -205,16 +213,16 @@ __device__ __forceinline__ void block_store_partials(const double (&s)[NV], doub
 }
 
 // total of partial component k over nblk blocks, computed by every thread that asks (small nblk, L2-resident)
-__device__ __forceinline__ void sum_partials(const double* __restrict__ part, int nblk, int off, int nv, double* out,
+__device__ __forceinline__ void sum_partials(const DevView& d, const fx_t* __restrict__ part, int nblk, int off, int nv, double* out,
                                              double* s_tmp) {
     // wave 0 reduces: lane-strided over blocks
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (wave == 0) {
         for (int k = 0; k < nv; ++k) {
-            double t = 0.0;
+            fx_t t = 0;
             for (int bIdx = lane; bIdx < nblk; bIdx += 64) t += part[(size_t)bIdx * RIGID_PART + off + k];
             t = wave_sum(t);
-            if (lane == 0) s_tmp[k] = t;
+            if (lane == 0) s_tmp[k] = (double)t / d.fx_scale;
         }
     }
     __syncthreads();
@@ -224,16 +232,16 @@ __device__ __forceinline__ void sum_partials(const double* __restrict__ part, in
 
 // sph_base.py:182-192 compute_com (mass = m_V0 * density): per-block partial sums
 __global__ __launch_bounds__(TPB) void k_rigid_sum(DevView d, const int* __restrict__ list, int n, int object_id,
-                                                   double* __restrict__ part) {
+                                                   fx_t* __restrict__ part) {
     const int tix = blockIdx.x * TPB + threadIdx.x;
-    double s[4] = {0, 0, 0, 0};
+    fx_t s[4] = {0, 0, 0, 0};
     if (tix < n) {
         const int i = list[tix];
         const int fl = __float_as_int(d.vf[i].w);
         if (sph_is_dynamic_rigid(fl) && sph_flags_object(fl) == object_id) {
             const float4 xm = d.xm[i];
             const float mass = d.m_V0 * d.aux[i].y;
-            s[0] = mass; s[1] = (double)(mass * xm.x); s[2] = (double)(mass * xm.y); s[3] = (double)(mass * xm.z);
+            s[0] = to_fx(d, mass); s[1] = to_fx(d, (double)(mass * xm.x)); s[2] = to_fx(d, (double)(mass * xm.y)); s[3] = to_fx(d, (double)(mass * xm.z));
         }
     }
     block_store_partials<4>(s, part, 0);
@@ -241,12 +249,12 @@ __global__ __launch_bounds__(TPB) void k_rigid_sum(DevView d, const int* __restr
 
 // sph_base.py:206-210: A = sum m (x - cm) (x_0 - cm_rest)^T, per-block partials
 __global__ __launch_bounds__(TPB) void k_rigid_A(DevView d, const int* __restrict__ list, int n, int object_id,
-                                                 double* __restrict__ part, int nblk) {
+                                                 fx_t* __restrict__ part, int nblk) {
     __shared__ double s_tmp[16];
     double tot[4];
-    sum_partials(part, nblk, 0, 4, tot, s_tmp);
+    sum_partials(d, part, nblk, 0, 4, tot, s_tmp);
     const int tix = blockIdx.x * TPB + threadIdx.x;
-    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    fx_t s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (tix < n) {
         const int i = list[tix];
         const int fl = __float_as_int(d.vf[i].w);
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(TPB) void k_rigid_A(DevView d, const int* __restric
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
-                for (int b = 0; b < 3; ++b) s[3 * a + b] = (double)(w * (p[a] * q[b]));
+                for (int b = 0; b < 3; ++b) s[3 * a + b] = to_fx(d, (double)(w * (p[a] * q[b])));
         }
     }
     block_store_partials<9>(s, part, 4);
@@ -376,12 +384,12 @@ __device__ __forceinline__ void rigid_cm_R(const double* tot, bool want_R, float
 }
 
 // mode 0: cm -> rigid_rest_cm[object_id] (sph_base.py:87-89) and out[0..2]; mode 2: cm -> out only
-__global__ __launch_bounds__(64) void k_rigid_cm_only(DevView d, const double* __restrict__ part, int nblk, int object_id,
+__global__ __launch_bounds__(64) void k_rigid_cm_only(DevView d, const fx_t* __restrict__ part, int nblk, int object_id,
                                                       int mode, float* __restrict__ out) {
     __shared__ double s_tmp[16];
     __shared__ float cmR[12];
     double tot[4];
-    sum_partials(part, nblk, 0, 4, tot, s_tmp);
+    sum_partials(d, part, nblk, 0, 4, tot, s_tmp);
     if (threadIdx.x == 0) {
         rigid_cm_R(tot, false, cmR);
         for (int k = 0; k < 3; ++k) {
@@ -394,11 +402,11 @@ __global__ __launch_bounds__(64) void k_rigid_cm_only(DevView d, const double* _
 // sph_base.py:212-221: R = polar(A) (+ identity fallback), x = cm + R (x_0 - cm_rest).  Every block derives cm and R
 // from the partials itself (a 3x3 f64 Jacobi is cheaper than another launch); block 0 also publishes them.
 __global__ __launch_bounds__(TPB) void k_rigid_apply(DevView d, const int* __restrict__ list, int n, int object_id,
-                                                     const double* __restrict__ part, int nblk, float* __restrict__ out) {
+                                                     const fx_t* __restrict__ part, int nblk, float* __restrict__ out) {
     __shared__ double s_tmp[16];
     __shared__ float cmR[12];
     double tot[13];
-    sum_partials(part, nblk, 0, 13, tot, s_tmp);
+    sum_partials(d, part, nblk, 0, 13, tot, s_tmp);
     if (threadIdx.x == 0) {
         rigid_cm_R(tot, true, cmR);
         if (blockIdx.x == 0)
@@ -428,9 +436,9 @@ __global__ __launch_bounds__(TPB) void k_rigid_apply(DevView d, const int* __res
 // ---- the same solve with the sums split over slabs (include/sph_hip.h: sph_rigid_partial_sums) ----
 // per-block partials of the 16 one-pass sums over the dynamic-rigid particles of `object_id` with index in [first,last)
 __global__ __launch_bounds__(TPB) void k_rigid_sum16(DevView d, const int* __restrict__ list, int n, int object_id,
-                                                     int first, int last, double* __restrict__ part) {
+                                                     int first, int last, fx_t* __restrict__ part) {
     const int tix = blockIdx.x * TPB + threadIdx.x;
-    double s[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    fx_t s[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (tix < n) {
         const int i = list[tix];
         const int fl = __float_as_int(d.vf[i].w);
@@ -443,23 +451,23 @@ __global__ __launch_bounds__(TPB) void k_rigid_sum16(DevView d, const int* __res
             const float x[3] = {xm.x, xm.y, xm.z};
             const float q[3] = {d.x0_cold[3 * pid] - rc[0], d.x0_cold[3 * pid + 1] - rc[1],
                                 d.x0_cold[3 * pid + 2] - rc[2]};
-            s[0] = mass;
+            s[0] = to_fx(d, mass);
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                s[1 + a] = (double)(mass * x[a]);  // same f32 product as k_rigid_sum
-                s[4 + a] = (double)mass * (double)q[a];
+                s[1 + a] = to_fx(d, (double)(mass * x[a]));  // same f32 product as k_rigid_sum
+                s[4 + a] = to_fx(d, (double)mass * (double)q[a]);
 #pragma unroll
-                for (int b = 0; b < 3; ++b) s[7 + 3 * a + b] = (double)mass * (double)x[a] * (double)q[b];
+                for (int b = 0; b < 3; ++b) s[7 + 3 * a + b] = to_fx(d, (double)mass * (double)x[a] * (double)q[b]);
             }
         }
     }
     block_store_partials<16>(s, part, 0);
 }
 
-__global__ __launch_bounds__(64) void k_rigid_total16(const double* __restrict__ part, int nblk, double* __restrict__ out) {
+__global__ __launch_bounds__(64) void k_rigid_total16(DevView d, const fx_t* __restrict__ part, int nblk, double* __restrict__ out) {
     __shared__ double s_tmp[16];
     double tot[16];
-    sum_partials(part, nblk, 0, 16, tot, s_tmp);
+    sum_partials(d, part, nblk, 0, 16, tot, s_tmp);
     if (threadIdx.x < 16) out[threadIdx.x] = nblk > 0 ? s_tmp[threadIdx.x] : 0.0;
 }
 
@@ -517,7 +525,10 @@ __global__ __launch_bounds__(TPB) void k_scatter_rest(float* __restrict__ x0_col
 __global__ __launch_bounds__(TPB) void k_build_dyn_list(DevView d, int* __restrict__ list, int* __restrict__ count) {
     const int i = blockIdx.x * TPB + threadIdx.x;
     if (i >= d.N) return;
-    if (sph_is_dynamic_rigid(__float_as_int(d.vf[i].w))) list[atomicAdd(count, 1)] = i;
+    if (sph_is_dynamic_rigid(__float_as_int(d.vf[i].w))) {
+        list[atomicAdd(count, 1)] = i;
+        atomicMax(reinterpret_cast<unsigned*>(count) + 1, __float_as_uint(fabsf(d.aux[i].y)));  // largest body density (bits of a non-negative float order like integers)
+    }
 }
 
 // ---- field insert / extract (sph_upload / sph_download) -------------------
@@ -659,9 +670,9 @@ int sphk_rigid_com(SphContext* c, int object_id, bool to_rest) {
     const int nb = n > 0 ? (n + TPB - 1) / TPB : 1;
     if (nb > c->rigid_part_blocks) return sph_fail(c, SPH_E_NOMEM, "rigid partial-sum buffer too small");
     // n == 0 (no dynamic particle, e.g. the rest cm of a static body): one block of zeros -> 0/0 = NaN like the reference
-    hipLaunchKernelGGL(k_rigid_sum, dim3(nb), dim3(TPB), 0, c->stream, d, c->dyn_list, n, object_id, c->rigid_part);
+    hipLaunchKernelGGL(k_rigid_sum, dim3(nb), dim3(TPB), 0, c->stream, d, c->dyn_list, n, object_id, (fx_t*)c->rigid_part);
     SPH_LAUNCH_CHECK(c);
-    hipLaunchKernelGGL(k_rigid_cm_only, dim3(1), dim3(64), 0, c->stream, d, c->rigid_part, nb, object_id, to_rest ? 0 : 2,
+    hipLaunchKernelGGL(k_rigid_cm_only, dim3(1), dim3(64), 0, c->stream, d, (const fx_t*)c->rigid_part, nb, object_id, to_rest ? 0 : 2,
                        c->rigid_R);
     SPH_LAUNCH_CHECK(c);
     return 0;
@@ -674,11 +685,11 @@ int sphk_rigid_solve(SphContext* c, int object_id) {
     DevView d = sph_view(c);
     const int n = c->n_dyn_host, nb = (n + TPB - 1) / TPB;
     if (nb > c->rigid_part_blocks) return sph_fail(c, SPH_E_NOMEM, "rigid partial-sum buffer too small");
-    hipLaunchKernelGGL(k_rigid_sum, dim3(nb), dim3(TPB), 0, c->stream, d, c->dyn_list, n, object_id, c->rigid_part);
+    hipLaunchKernelGGL(k_rigid_sum, dim3(nb), dim3(TPB), 0, c->stream, d, c->dyn_list, n, object_id, (fx_t*)c->rigid_part);
     SPH_LAUNCH_CHECK(c);
-    hipLaunchKernelGGL(k_rigid_A, dim3(nb), dim3(TPB), 0, c->stream, d, c->dyn_list, n, object_id, c->rigid_part, nb);
+    hipLaunchKernelGGL(k_rigid_A, dim3(nb), dim3(TPB), 0, c->stream, d, c->dyn_list, n, object_id, (fx_t*)c->rigid_part, nb);
     SPH_LAUNCH_CHECK(c);
-    hipLaunchKernelGGL(k_rigid_apply, dim3(nb), dim3(TPB), 0, c->stream, d, c->dyn_list, n, object_id, c->rigid_part, nb,
+    hipLaunchKernelGGL(k_rigid_apply, dim3(nb), dim3(TPB), 0, c->stream, d, c->dyn_list, n, object_id, (const fx_t*)c->rigid_part, nb,
                        c->rigid_R);
     SPH_LAUNCH_CHECK(c);
     return 0;
@@ -710,7 +721,7 @@ int sphk_init_pid(SphContext* c) {
 }
 
 int sphk_build_dyn_list(SphContext* c) {
-    SPH_HIP(c, hipMemsetAsync(c->dyn_count, 0, sizeof(int), c->stream));
+    SPH_HIP(c, hipMemsetAsync(c->dyn_count, 0, 2 * sizeof(int), c->stream));
     if (c->N > 0) {
         DevView d = sph_view(c);
         hipLaunchKernelGGL(k_build_dyn_list, dim3((c->N + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, c->dyn_list,
@@ -727,10 +738,10 @@ int sphk_rigid_partial16(SphContext* c, int object_id, int first, int count, dou
     if (nb > c->rigid_part_blocks) return sph_fail(c, SPH_E_NOMEM, "rigid partial-sum buffer too small");
     if (nb > 0) {
         hipLaunchKernelGGL(k_rigid_sum16, dim3(nb), dim3(TPB), 0, c->stream, d, c->dyn_list, n, object_id, first,
-                           first + count, c->rigid_part);
+                           first + count, (fx_t*)c->rigid_part);
         SPH_LAUNCH_CHECK(c);
     }
-    hipLaunchKernelGGL(k_rigid_total16, dim3(1), dim3(64), 0, c->stream, c->rigid_part, nb, out);
+    hipLaunchKernelGGL(k_rigid_total16, dim3(1), dim3(64), 0, c->stream, d, (const fx_t*)c->rigid_part, nb, out);
     SPH_LAUNCH_CHECK(c);
     return 0;
 }

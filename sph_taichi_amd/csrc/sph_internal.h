@@ -46,6 +46,7 @@ struct DevView {
     float w_zero, w_d;  // W(0), W(d)
     float m_eps;        // DFSPH.py:17
     float m_u;          // the common fluid particle mass (uniform-fluid force path)
+    double fx_scale;    // 2^S of the fixed-point shape-matching sums (sph_integrate.hip)
     float whx, why, whz;  // upper wall planes (domain_size - padding), for the advect fused into the force sweep
     int fuse_advect;    // GM_FORCE_FUSED_U finish also integrates its fluid targets (WCSPH.py:143-149 + fluid walls)
     int write_sg;       // density finish also writes the stg (/ gat) records of the one-gather sweeps
@@ -61,6 +62,7 @@ struct DevView {
     float4* gat;  // (vx, vy, vz, p/rho^2) (fluid) or (v, 1 if dynamic else 0) (solid) } staged / gathered records
     float* kbuf;  // DFSPH: k_j = b_j * dfsph_factor_j (same memory as gat)
     float4* acc;
+    long long* acc_fx;  // [3 N] two-way coupling reactions on dynamic rigid particles, 2^32 fixed point (couple_scatter / k_fold_coupling)
     int* key;
     int* cell_end;
     const float* x0_cold;
@@ -99,6 +101,7 @@ struct SphContext {
     float4* gat;
     float4* acc;
     float4* acc_tmp;
+    long long* acc_fx;   // [3 cap] fixed-point accumulators of the coupling reactions
     int* cell_end;     // [G+1] the CURRENT cell array (one of cell_buf[])
     int* cell_buf[2];  // two cell arrays: while one serves the sweeps, the scatter zeroes the other for the next histogram
     int cell_cur;
@@ -119,6 +122,7 @@ struct SphContext {
     int* dyn_list;     // [cap] sorted-order indices of dynamic rigid particles
     int* dyn_count;    // device counter
     int n_dyn_host;    // number of dynamic rigid particles (constant; counted at upload)
+    int rigid_fx_exp;  // S of the fixed-point shape-matching sums: set with n_dyn_host from the count, the largest body density and the domain size
     double* rigid_part;   // [rigid_part_blocks][16] per-block partial sums of the shape-matching reductions
     int rigid_part_blocks;
     float* rigid_R;    // [12] cm[3] + R[9]
@@ -195,6 +199,8 @@ int sphk_df_predict_velocity(SphContext* c);
 int sphk_df_advect(SphContext* c, bool fused_fluid_walls);
 int sphk_advect(SphContext* c, bool fused_fluid_walls);
 int sphk_advect_dyn_list(SphContext* c);  // dynamic rigid particles only
+int sphk_fold_coupling_range(SphContext* c, int first, int count);  // ... of a record range, on the current sweep stream
+int sphk_fold_coupling(SphContext* c);    // acc of the dynamic rigid particles += their fixed-point reaction sums (which are zeroed)
 int sphk_advect_range(SphContext* c, int first, int count);
 int sphk_enforce_boundary(SphContext* c, int particle_type);
 int sphk_rigid_com(SphContext* c, int object_id, bool to_rest);

@@ -134,21 +134,44 @@ __global__ __launch_bounds__(TPB) void k_stable_scatter(DevView d, const int* __
     // the OTHER cell array (the previous step's, dead by now) is zeroed here for the next histogram: 2 MB of stores in
     // a 180 MB kernel instead of a memset launch of its own (~10 us per step)
     for (int z = s; z < zero_n4; z += gridDim.x * TPB) zero_dst[z] = make_int4(0, 0, 0, 0);
-    if (s >= d.N) return;
-    const int i = idx_unstable[s];
-    const int c = d.key[i];
+    const bool live = s < d.N;
+    const int lane = threadIdx.x & 63;
+    const int i = live ? idx_unstable[s] : 0;
+    const int c = live ? d.key[i] : 0;
     const int b = c > 0 ? d.cell_end[c - 1] : 0;
-    const int e = d.cell_end[c];
+    const int e = live ? d.cell_end[c] : 0;
+    const int my = live ? (d.sort_by_pid ? __float_as_int(d.aux[i].w) : i) : 0;  // the key a cell is ordered by: previous index (the
+    // reference's serial order) or persistent id (the canonical order two ranks agree on, slab DFSPH)
     int rank = s - b;  // virtual cell G (dropped slab strays): any order will do, and the cell can be huge
-    if (c != d.G) {
+    // Rank among the cell's members = how many of them have a smaller key.  A lane walks its own cell (<= ~30 members,
+    // L1-resident) -- but a crowded cell (a collapsed scene, a pile-up in a corner) would keep ONE lane busy for
+    // hundreds of reads while 63 idle: cells with more than 64 members are ranked by the whole wave, one target at a
+    // time, every lane taking a 64th of the members.
+    const bool ranked = live && c != d.G;
+    const bool crowded = ranked && e - b > 64;
+    if (ranked && !crowded) {
         rank = 0;
-        if (d.sort_by_pid) {  // canonical order two ranks agree on (slab DFSPH), not the reference's
-            const int my = __float_as_int(d.aux[i].w);
+        if (d.sort_by_pid) {
             for (int t = b; t < e; ++t) rank += (__float_as_int(d.aux[idx_unstable[t]].w) < my) ? 1 : 0;
         } else {
-            for (int t = b; t < e; ++t) rank += (idx_unstable[t] < i) ? 1 : 0;
+            for (int t = b; t < e; ++t) rank += (idx_unstable[t] < my) ? 1 : 0;
         }
     }
+    unsigned long long todo = __ballot(crowded);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        const int bb = __shfl(b, src, 64), ee = __shfl(e, src, 64), kk = __shfl(my, src, 64);
+        int cnt = 0;
+        for (int t = bb + lane; t < ee; t += 64) {
+            const int v = idx_unstable[t];
+            cnt += ((d.sort_by_pid ? __float_as_int(d.aux[v].w) : v) < kk) ? 1 : 0;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        if (lane == src) rank = cnt;
+    }
+    if (!live) return;
     const int dst = b + rank;  // == grid_ids_new[i] of a serial run (particle_system.py:330)
     const float4 xm = d.xm[i];
     const float4 vf = d.vf[i];

@@ -103,8 +103,15 @@ def test_c3_armadillo_equivalent_dynamic_bodies():
     err = scenes.rel_l2(x, x_ref)
     assert err <= 1e-4, f"C3 position rel-L2 after {n} steps: {err:.3e}"
     rigid = sc.arrays["material"] == 0
-    assert scenes.rel_l2(x[rigid], x_ref[rigid]) <= 2e-5
+    assert scenes.rel_l2(x[rigid], x_ref[rigid]) <= 2e-5            # diagnostic: the oracle with f64 accumulators
     assert scenes.rel_l2(x, o32.by_pid("x")) <= 1e-4
+    # The bodies alone against the reference-order f32 oracle (the reference's own arithmetic on a serial backend): its
+    # f32 running sums over 5,917 terms per body carry ~1e-5 of summation error per step, the HIP path's exact sums
+    # none, so THIS difference is the reference's rounding, not ours -- measured 1.4e-4 after 30 steps (r03, value in
+    # gpurun_out/parity_curves.json) where the f64-accumulating oracle above agrees to 2e-5.  Stated bound: 2e-4.
+    e32 = scenes.rel_l2(x[rigid], o32.by_pid("x")[rigid])
+    _record_curve("c3_bodies_vs_f32_reference_order_oracle", [(n, e32)], bound=2e-4)
+    assert e32 <= 2e-4, f"C3 bodies vs the f32 reference-order oracle after {n} steps: {e32:.3e}"
     v = scenes.ps_by_pid(ps, "v")
     free_fall = -5.0 - 9.81 * n * 4e-4
     light = sc.arrays["object_id"] == 3                     # density 300: decelerated hard by the fluid
@@ -172,6 +179,64 @@ def test_dfsph_dragon_bath_equivalent():
     assert abs(st["total_iterations"] - sum(b + 1 for _, b in its)) <= 1
     assert scenes.rel_l2(scenes.ps_by_pid(ps, "x"), o.by_pid("x")) <= 1e-4
     assert np.array_equal(np.sort(ps.pid.to_numpy()), np.arange(sc.particle_max_num))
+    ps.close()
+
+
+def test_high_fluid_wcsph_scene():
+    """data/scenes/high_fluid_wcsph.json as it is (VERDICT r02 "missing" #4): a 0.6 x 5.4 x 0.6 column of 30 x 270 x 30 =
+    243,000 particles in a (2, 6, 2) tank -- 50 x 150 x 50 cells, tall and narrow: y is the middle axis of the flatten
+    order, so the brick list's column groups are few and their z extent short.  100 steps against the oracle."""
+    sd = {"Configuration": dict(scenes.BASE_CFG, domainEnd=[2.0, 6.0, 2.0]),
+          "FluidBlocks": [{"objectId": 0, "start": [0.0, 0.0, 0.0], "end": [0.6, 5.4, 0.6], "translation": [0.1, 0.1, 0.1],
+                           "scale": [1, 1, 1], "velocity": [0.0, 0.0, 0.0], "density": 1000.0, "color": [50, 100, 200]}]}
+    cfg, sc = scenes.build(sd)
+    assert sc.particle_max_num == 30 * 270 * 30 and tuple(sc.geom.grid_num) == (50, 150, 50)
+    o = scenes.make_oracle(cfg, sc, omp_threads=_threads())
+    ps, solver = scenes.make_ps(sd)
+    o.initialize(); solver.initialize()
+    assert np.array_equal(ps.grid_ids.to_numpy(), o["grid_ids"]) and np.array_equal(ps.pid.to_numpy(), o["pid"])
+    curve = []
+    for n in (25, 50, 100):
+        k = n - (curve[-1][0] if curve else 0)
+        o.step(k); solver.step(k)
+        curve.append((n, scenes.rel_l2(scenes.ps_by_pid(ps, "x"), o.by_pid("x"))))
+    _record_curve("high_fluid_wcsph_243k", curve)
+    assert curve[-1][1] <= 1e-4, curve
+    from sph_taichi_amd import _lib
+    st = _lib.SphStats()
+    ps._call("sph_get_stats", st)
+    assert st.lds_overflow_targets == 0 and st.list_overflow_targets == 0
+    assert np.array_equal(np.sort(ps.pid.to_numpy()), np.arange(sc.particle_max_num))
+    ps.close()
+
+
+def test_dragon_bath_dynamic_dfsph_scene():
+    """data/scenes/dragon_bath_dynamic_dfsph.json equivalent (VERDICT r02 "missing" #4): the dragon (18,496 voxels from the
+    fixture) as a DYNAMIC shape-matched body under DFSPHSolver, dt = 4e-3, next to the falling 423,500-particle block:
+    boundary volumes of a moving body, shape matching of 18 k particles, the solid wall pass (the dragon starts 1 cm
+    above the floor padding and lands within the first steps), DFSPH's coupling terms -- against the oracle."""
+    sd = dragon_bath_scene()
+    sd["RigidBodies"][0]["isDynamic"] = True
+    sd["Configuration"]["simulationMethod"] = 4
+    sd["Configuration"]["timeStepSize"] = 0.004
+    cfg, sc = scenes.build(sd)
+    o = scenes.make_oracle(cfg, sc, omp_threads=_threads())
+    ps, solver = scenes.make_ps(sd)
+    o.initialize(); solver.initialize()
+    steps = 4
+    its = []
+    for _ in range(steps):
+        o.step(1)
+        its.append((o.s.last_iterations_v, o.s.last_iterations))
+    solver.step(steps)
+    st = solver.stats()
+    assert abs(st["total_iterations_v"] - sum(a + 1 for a, _ in its)) <= 1
+    assert abs(st["total_iterations"] - sum(b + 1 for _, b in its)) <= 1
+    x, xo = scenes.ps_by_pid(ps, "x"), o.by_pid("x")
+    assert scenes.rel_l2(x, xo) <= 1e-4
+    body = sc.arrays["material"] == 0
+    assert np.abs(x[body] - sc.arrays["x"][body]).max() > 1e-4, "the dragon did not move"
+    assert scenes.rel_l2(x[body], xo[body]) <= 1e-5
     ps.close()
 
 

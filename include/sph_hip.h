@@ -209,7 +209,7 @@ typedef struct SphStats {
     int64_t list_entries;          /* sum of their neighbour-list lengths (superset filter: includes the particle
                                       itself and pairs within 1e-4 h beyond h) */
     int32_t max_list;              /* longest list */
-    int32_t list_overflow_targets; /* lists longer than the hand-off capacity (63): the force sweep walks the cells */
+    int32_t list_overflow_targets; /* lists longer than the hand-off capacity (95): the force sweep walks the cells */
     int32_t lds_overflow_targets;  /* targets of bricks whose shell did not fit the LDS tile: both sweeps walk the cells */
     int32_t max_cell_occupancy;    /* particles in the fullest cell */
     int32_t nonempty_cells;

@@ -86,40 +86,39 @@ def lib(timing: bool = False):
 
 
 def _bind(L):
-    if True:
-        ps = C.POINTER(_State)
-        for name in ("update_grid_id", "prefix_sum", "counting_sort", "initialize_particle_system",
-                     "compute_static_boundary_volume", "compute_moving_boundary_volume",
-                     "compute_densities", "compute_non_pressure_forces", "compute_pressure_forces",
-                     "advect", "substep", "dfsph_compute_densities", "dfsph_compute_non_pressure_forces",
-                     "dfsph_compute_factor", "dfsph_compute_density_change", "dfsph_compute_density_adv",
-                     "dfsph_divergence_solver_iteration_kernel", "dfsph_pressure_solve_iteration_kernel",
-                     "dfsph_divergence_solve", "dfsph_pressure_solve", "dfsph_predict_velocity", "dfsph_advect",
-                     "dfsph_substep"):
-            f = getattr(L, "oracle_" + name)
-            f.argtypes = [ps]
-            f.restype = None
-        L.oracle_dfsph_compute_density_error.argtypes = [ps, C.c_float]
-        L.oracle_dfsph_compute_density_error.restype = C.c_float
-        L.oracle_dfsph_multiply_time_step.argtypes = [ps, C.c_float]
-        L.oracle_dfsph_multiply_time_step.restype = None
-        for name in ("dfsph_divergence_solver_iteration", "dfsph_pressure_solve_iteration"):
-            f = getattr(L, "oracle_" + name)
-            f.argtypes = [ps]
-            f.restype = C.c_double
-        L.oracle_enforce_boundary_3D.argtypes = [ps, C.c_int32]
-        L.oracle_compute_rigid_rest_cm.argtypes = [ps, C.c_int32]
-        L.oracle_solve_constraints.argtypes = [ps, C.c_int32, _pf]
-        L.oracle_solve_rigid_body.argtypes = [ps, _pi, C.c_int32]
-        L.oracle_step.argtypes = [ps, _pi, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
-        L.oracle_initialize.argtypes = [ps, _pi, C.c_int32]
-        L.oracle_cubic_kernel.argtypes = [ps, C.c_float]
-        L.oracle_cubic_kernel.restype = C.c_float
-        L.oracle_cubic_kernel_derivative.argtypes = [ps, _pf, _pf]
-        L.oracle_polar_rotation.argtypes = [_pf, _pf]
-        L.oracle_sizeof_state.restype = C.c_int32
-        L.oracle_max_threads.restype = C.c_int32
-        assert L.oracle_sizeof_state() == C.sizeof(_State), "OracleState layout mismatch"
+    ps = C.POINTER(_State)
+    for name in ("update_grid_id", "prefix_sum", "counting_sort", "initialize_particle_system",
+                 "compute_static_boundary_volume", "compute_moving_boundary_volume",
+                 "compute_densities", "compute_non_pressure_forces", "compute_pressure_forces",
+                 "advect", "substep", "dfsph_compute_densities", "dfsph_compute_non_pressure_forces",
+                 "dfsph_compute_factor", "dfsph_compute_density_change", "dfsph_compute_density_adv",
+                 "dfsph_divergence_solver_iteration_kernel", "dfsph_pressure_solve_iteration_kernel",
+                 "dfsph_divergence_solve", "dfsph_pressure_solve", "dfsph_predict_velocity", "dfsph_advect",
+                 "dfsph_substep"):
+        f = getattr(L, "oracle_" + name)
+        f.argtypes = [ps]
+        f.restype = None
+    L.oracle_dfsph_compute_density_error.argtypes = [ps, C.c_float]
+    L.oracle_dfsph_compute_density_error.restype = C.c_float
+    L.oracle_dfsph_multiply_time_step.argtypes = [ps, C.c_float]
+    L.oracle_dfsph_multiply_time_step.restype = None
+    for name in ("dfsph_divergence_solver_iteration", "dfsph_pressure_solve_iteration"):
+        f = getattr(L, "oracle_" + name)
+        f.argtypes = [ps]
+        f.restype = C.c_double
+    L.oracle_enforce_boundary_3D.argtypes = [ps, C.c_int32]
+    L.oracle_compute_rigid_rest_cm.argtypes = [ps, C.c_int32]
+    L.oracle_solve_constraints.argtypes = [ps, C.c_int32, _pf]
+    L.oracle_solve_rigid_body.argtypes = [ps, _pi, C.c_int32]
+    L.oracle_step.argtypes = [ps, _pi, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+    L.oracle_initialize.argtypes = [ps, _pi, C.c_int32]
+    L.oracle_cubic_kernel.argtypes = [ps, C.c_float]
+    L.oracle_cubic_kernel.restype = C.c_float
+    L.oracle_cubic_kernel_derivative.argtypes = [ps, _pf, _pf]
+    L.oracle_polar_rotation.argtypes = [_pf, _pf]
+    L.oracle_sizeof_state.restype = C.c_int32
+    L.oracle_max_threads.restype = C.c_int32
+    assert L.oracle_sizeof_state() == C.sizeof(_State), "OracleState layout mismatch"
     return L
 
 

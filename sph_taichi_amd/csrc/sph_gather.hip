@@ -1618,7 +1618,7 @@ static int launch_sweep(SphContext* c) {
     if (c->N <= 0) return 0;
     if (c->opt_gather_impl == 0 || c->p.grid_num[2] > SPH_BRICK_MAX_NZ) return launch_simple<MODE>(c, nullptr, c->N);
     int rc = launch_brick<MODE>(c);
-    if (!rc && mode_writes_list<MODE>()) c->lists_valid = true;
+    if (!rc && mode_writes_list<MODE>()) { c->lists_valid = true; c->gcnt_written = true; }
     if (!rc && MODE == GM_DENSITY_EOS) { c->stg_kind = c->uniform_state == 1 ? 1 : 0; if (c->stg_kind == 1) c->aux_stale = true; }
     return rc;
 }
@@ -1645,7 +1645,7 @@ static int launch_df(SphContext* c) {
         else rc = launch_brick_cfg<MODE, Cfg0>(c);
     } else
         rc = launch_brick_cfg<MODE, Cfg0>(c);
-    if (!rc && mode_writes_list<MODE>()) { c->lists_valid = true; c->stg_kind = 2; c->k_kind = 0; }
+    if (!rc && mode_writes_list<MODE>()) { c->lists_valid = true; c->gcnt_written = true; c->stg_kind = 2; c->k_kind = 0; }
     if (!rc && MODE == GM_DF_DENSITY_CHANGE) c->k_kind = 1;
     if (!rc && MODE == GM_DF_DENSITY_ADV) c->k_kind = 2;
     return rc;
@@ -1709,7 +1709,7 @@ __global__ __launch_bounds__(TPB) void k_stats(DevView d, const unsigned char* _
     const int i = blockIdx.x * TPB + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int tgt = 0, len = 0, lovf = 0, sovf = 0, occ = 0, ne = 0;
-    if (i < d.N && sph_is_fluid(__float_as_int(d.vf[i].w))) {
+    if (gcnt && i < d.N && sph_is_fluid(__float_as_int(d.vf[i].w))) {
         const int c = gcnt[i];
         tgt = 1;
         if (c == SPH_CNT_WALK) sovf = 1;
@@ -1749,7 +1749,9 @@ int sphk_stats(SphContext* c, SphStats* out) {
     unsigned long long h[7];
     SPH_HIP(c, hipMemsetAsync(dev, 0, sizeof(h), c->stream));
     const int n = max(c->N, c->G);
-    hipLaunchKernelGGL(k_stats, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, c->gcnt, dev);
+    // (list lengths only if a brick density sweep wrote gcnt for the current order: ADVICE r02 -- otherwise the
+    // fields stay 0 instead of showing stale or never-written bytes)
+    hipLaunchKernelGGL(k_stats, dim3((n + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, c->gcnt_written ? c->gcnt : nullptr, dev);
     SPH_LAUNCH_CHECK(c);
     SPH_HIP(c, hipMemcpyAsync(h, dev, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     SPH_HIP(c, hipStreamSynchronize(c->stream));

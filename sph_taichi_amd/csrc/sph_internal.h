@@ -7,7 +7,7 @@
 //   aux[cap] float4 = (m, density, pressure, bits(pid)) hot, ping-pong
 //   eos[cap] float4 = (p/rho^2, m/rho_raw, m, rho)    written by density+EOS, read by force
 //                     (DFSPH: (dfsph_factor, density_adv, m, rho))
-//   glist[64*cap] u16, gcnt[cap] u8                   neighbour lists: row k of particle i at glist[k*cap + i]
+//   glist[96*cap] u16, gcnt[cap] u8                   neighbour lists (SPH_GLIST_ROWS rows): row k of particle i at glist[k*cap + i]
 //   acc[cap] float4 = (ax, ay, az, 0)
 //   key[cap] int    = grid_ids                        ping-pong
 //   x0_cold [3*cap] f32, color_cold [3*cap] i32       indexed by pid, never moved
@@ -130,6 +130,7 @@ struct SphContext {
     size_t stage_bytes;
     bool have_keys, have_prefix, sorted;
     bool lists_valid;   // glist/gcnt describe the CURRENT positions and order (written by a list-writing brick sweep)
+    bool gcnt_written;  // gcnt was written by a brick density sweep since the last sort (sph_get_stats reports list lengths only then)
     int stg_kind;       // what stg / gat hold for the current positions: 0 nothing, 1 the WCSPH records of
                         // GM_DENSITY_EOS, 2 the DFSPH record (x, y, z, +m_V fluid / -m_V solid) of GM_DF_DENSITY
     int k_kind;         // gat-as-float holds k_j = b_j * factor_j: 0 no, 1 b = density_adv, 2 b = density_adv - 1

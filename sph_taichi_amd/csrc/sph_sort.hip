@@ -231,6 +231,7 @@ int sphk_sort_scatter(SphContext* c, bool sort_acc) {
     c->brick_count_zero = true;
     c->cur = o;
     sph_invalidate_lists(c);
+    c->gcnt_written = false;
     c->aux_stale = false;  // (eos2 is in the old order: whoever needed density / pressure called sph_ensure_aux before)
     if (sort_acc) {
         float4* t = c->acc;

@@ -413,6 +413,7 @@ class SlabSolver:
         self.check_every = int(check_every)
         self._shift = (0, 0)        # pending move of (left cut, right cut), applied at the next exchange
         self._recut_due = False
+        self._guard_due = False
         self.ps = ParticleSystem(cfg, device=device, stream=stream, scene_dir=scene_dir,
                                  slab=dict(x_lo=self.x_lo, x_hi=self.x_hi, halo=halo, capacity=capacity,
                                            nx_slack=int(nx_slack) if self.recut_every > 0 else 0))
@@ -594,7 +595,9 @@ class SlabSolver:
                  C.c_void_p(recv_right.data_ptr()) if n_right > 0 else None, n_right, layers, nl, 2 if density else 0)
         self._need_density = not density
         self._read_offsets(begin=False)
-        if not self._recut_due:
+        # a step that ends with a collective (conservation guard, re-cut) announces AFTER it: no collective may sit
+        # between the posted count messages and their payload on the same communicator
+        if not (self._recut_due or self._guard_due):
             self.announce()
 
     def check_conservation(self):
@@ -607,9 +610,20 @@ class SlabSolver:
                                "A particle crossed more than one cell layer in a step (time step too large for the "
                                f"flow speed?) -- the halo exchange carries {self.halo + 1} layers per side")
 
-    def _guard(self):
-        if self.check_every > 0 and (self.steps_done % self.check_every == 0 or self._recut_due):
+    def _begin_step(self):
+        """Which collectives end the step that is about to run (decided before its exchange is announced)."""
+        self._recut_due = self.recut_every > 0 and (self.steps_done + 1) % self.recut_every == 0
+        self._guard_due = self.check_every > 0 and ((self.steps_done + 1) % self.check_every == 0 or self._recut_due)
+
+    def _end_step(self):
+        """The deferred collectives, then the announcement of the next exchange's counts."""
+        if self._guard_due:
             self.check_conservation()
+        if self._recut_due:
+            self.recut_now()                  # (announces)
+        elif self._guard_due:
+            self.announce()
+        self._guard_due = False
 
     def announce(self):
         if getattr(self, "transport", None) is not None and hasattr(self.transport, "start_counts"):
@@ -786,15 +800,13 @@ class SlabSolver:
         hm = self.host_ms
         if self.dfsph:
             for _ in range(n):
-                self._recut_due = self.recut_every > 0 and (self.steps_done + 1) % self.recut_every == 0
+                self._begin_step()
                 self._serve(self._dfsph_step_requests())
                 self.steps_done += 1
-                self._guard()
-                if self._recut_due:
-                    self.recut_now()
+                self._end_step()
             return
         for _ in range(n):
-            self._recut_due = self.recut_every > 0 and (self.steps_done + 1) % self.recut_every == 0
+            self._begin_step()
             t0 = time.perf_counter()
             if self.dynamic_bodies:
                 self.phase_forces(pack=False)
@@ -807,9 +819,7 @@ class SlabSolver:
             t2 = time.perf_counter()
             self.phase_advance(rL, mL, rR, mR)
             self.steps_done += 1
-            self._guard()
-            if self._recut_due:
-                self.recut_now()
+            self._end_step()
             t3 = time.perf_counter()
             hm["forces_pack"] += (t1 - t0) * 1e3; hm["exchange"] += (t2 - t1) * 1e3; hm["advance"] += (t3 - t2) * 1e3
             hm["steps"] += 1
@@ -974,8 +984,10 @@ def run_slab_bench(args, rank, world, local_rank):
     if dfsph:                                     # supplementary line, like bench.py --solver dfsph at N = 1
         sd["Configuration"]["simulationMethod"] = 4
         sd["Configuration"]["timeStepSize"] = 0.004
+    # (check_every = 0: the conservation guard is a blocking all-reduce + host read; the bench scene is balanced and
+    # slow -- no particle can outrun the halo -- so the guard stays out of the timed region)
     s = SlabSolver(sd, rank, world, device=local_rank, gather_impl=args.gather_impl, brick_shape=args.brick_shape,
-                   recut_every=getattr(args, "recut_every", 0))
+                   recut_every=getattr(args, "recut_every", 0), check_every=0)
     # The exchange: RCCL behind the C ABI (NativeTransport: enqueued on the device, no host wait inside a step) when
     # the job runs on RCCL; torch.distributed P2P otherwise (gloo: several ranks sharing one GPU) or on request
     # (SPH_TRANSPORT=torch).

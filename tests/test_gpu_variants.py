@@ -43,7 +43,7 @@ def test_variant_follows_the_oracle(variant):
 
 @pytest.mark.parametrize("variant", [1, 2, 4, 7, 15, 21, 31, 61, 125, 189, 285])
 def test_variant_on_crowded_cells(variant):
-    """12^3 particles in a (1.5 h)^3 box: > 63 neighbours each, so every list overflows (the two-phase density must
+    """12^3 particles in a (1.5 h)^3 box: > 95 neighbours each, so every list overflows (the two-phase density must
     fall back to the exact walk; the range-checked list stores must drop rows >= LISTCAP and nothing else)."""
     sd = scenes.fluid_only(counts=(12, 12, 12), start=(0.3, 0.3, 0.3))
     cfg, sc = scenes.build(sd)

@@ -1,21 +1,59 @@
 #!/bin/bash
-# One GPU-box visit: parity tests, bench (+ variant sweep), rocprofv3 kernel stats.
-# Usage (from the repo root on the GPU box): bash tools/gpu_round.sh [tag]
-TAG=${1:-r01}
+# One parameterised GPU visit (replaces the per-call scripts of rounds 1-2).  Usage: bash tools/gpu_round.sh <tag> [parts]
+#   parts (default "tests pmc kstats bench variants"):
+#     tests    : pytest -m gpu
+#     pmc      : rocprofv3 PMC passes, from rest and settled -> gpurun_out/<tag>/pmc_traffic.json (+ summaries)
+#     kstats   : rocprofv3 kernel-trace stats of the default bench line's two states
+#     bench    : the default bench line + the other workloads
+#     variants : A/B table  partition (adaptive / fixed bricks) x emission (group-sorted / ring)
+#     native   : kernel trace of the one-rank native RCCL worker
+TAG=${1:-round}; shift
+PARTS=${*:-tests pmc kstats bench variants}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out
+OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
 export TMPDIR=/tmp
-nproc > $OUT/nproc.txt
-rocm-smi --showproductname 2>/dev/null | head -20 > $OUT/gpu.txt
-echo "== pytest -m gpu" 
-timeout 1500 python -m pytest tests -m gpu -q --timeout=900 -x 2>&1 | tail -40 | tee $OUT/pytest_$TAG.log
-echo "== bench"
-timeout 900 python bench.py --steps 100 --warmup 10 --sweep > $OUT/bench_$TAG.json 2> $OUT/bench_$TAG.err
-tail -5 $OUT/bench_$TAG.err; cat $OUT/bench_$TAG.json
-echo "== rocprof"
-cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_$TAG -o prof -- python $R/bench.py --steps 50 --warmup 5 --cpu-steps 0 > $OUT/rocprof_$TAG.log 2>&1
-ls $OUT/prof_$TAG 2>/dev/null | head
-find $OUT/prof_$TAG -name "*kernel_stats*" | head -1 | xargs -r head -30
+has() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
+if has tests; then
+  timeout 900 python -m pytest tests -m gpu -q --durations=5 > $OUT/pytest_gpu.log 2>&1; echo "gpu pytest rc=$?"
+  tail -n 10 $OUT/pytest_gpu.log
+  cp gpurun_out/parity_curves.json $OUT/ 2>/dev/null; cp gpurun_out/parity_errors.json $OUT/ 2>/dev/null
+fi
+if has pmc; then
+  bash tools/gpu_pmc.sh ${TAG}_rest > $OUT/pmc_rest.log 2>&1; tail -n 2 $OUT/pmc_rest.log
+  bash tools/gpu_pmc.sh ${TAG}_settled --settle 2000 > $OUT/pmc_settled.log 2>&1; tail -n 2 $OUT/pmc_settled.log
+  python tools/refresh_pmc.py gpurun_out/pmc_${TAG}_rest $OUT/pmc_traffic.json --settled gpurun_out/pmc_${TAG}_settled --tail 20 > $OUT/pmc_brief.json 2> $OUT/refresh.err; echo "refresh rc=$?"
+  rm -rf gpurun_out/pmc_${TAG}_rest gpurun_out/pmc_${TAG}_settled
+  cp $OUT/pmc_traffic.json profiles/pmc_traffic.json
+  head -c 1500 $OUT/pmc_brief.json
+fi
+if has kstats; then
+  bash tools/gpu_kstats.sh $TAG "--steps 60 --warmup 5 --min-seconds 0 --settled-after 0" "--steps 60 --warmup 5 --settle 2000 --settled-after 0"
+fi
+if has bench; then
+  timeout 300 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 1200 $OUT/bench_default.json; echo
+  timeout 200 python bench.py --steps 20 --warmup 5 --cpu-steps 0 > $OUT/bench_driver_args.json 2>> $OUT/bench.err
+  for w in c1_dambreak_262k c2_dragon_bath c3_armadillo_equiv; do
+    timeout 200 python bench.py --steps 100 --warmup 10 --cpu-steps 0 --workload $w --settled-after 0 --min-seconds 0 > $OUT/bench_$w.json 2>> $OUT/bench.err
+  done
+  timeout 200 python bench.py --steps 100 --warmup 10 --cpu-steps 0 --workload c1_dambreak_262k --settle 2500 --settled-after 0 > $OUT/bench_c1_developed.json 2>> $OUT/bench.err
+  timeout 300 python bench.py --steps 30 --warmup 3 --cpu-steps 0 --solver dfsph > $OUT/bench_dfsph_c3p.json 2>> $OUT/bench.err
+  for f in driver_args c1_dambreak_262k c2_dragon_bath c3_armadillo_equiv c1_developed dfsph_c3p; do python -c "import json;d=json.load(open('$OUT/bench_$f.json'));print('$f',d['value'],d['ms_per_step'],d['breakdown_ms'])"; done
+fi
+if has variants; then
+  timeout 600 python tools/variant_sweep.py --variants 189,285 --shapes 1,0 --steps 60 --settled-steps 80 --out $OUT/variants_partition_x_emission.json > $OUT/variants.log 2>&1
+  grep -v "^$" $OUT/variants.log | grep -v amdgpu | tail -n 10
+fi
+if has native; then
+  python - <<'P'
+import json, sys
+sys.path.insert(0, "tests")
+import scenes
+json.dump(scenes.fluid_with_rigid_bodies("/tmp/cube_native.obj"), open("/tmp/scene_native.json", "w"))
+P
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_native -o prof --output-format csv -- python $R/tests/slab_worker.py native1 0 1 29611 /tmp/res_native.npz /tmp/scene_native.json 12 > $OUT/rocprof_native.log 2>&1 )
+  f=$(find $OUT/prof_native -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/native_rccl_one_rank_kernel_stats.csv && grep -i "nccl\|rccl" "$f" | cut -c1-200
+  rm -rf $OUT/prof_native
+  timeout 300 python tools/slab_overhead.py > $OUT/slab_overhead_world1.txt 2>&1; grep -v amdgpu $OUT/slab_overhead_world1.txt
+fi

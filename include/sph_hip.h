@@ -129,19 +129,19 @@ enum SphOption {
                                   order (previous index) is kept on a single GPU; slab ranks running DFSPH need an order
                                   that the owner of a boundary band and the neighbour holding it as ghosts agree on, so
                                   that ghost velocities can be refreshed record for record */,
-    SPH_OPT_KERNEL_VARIANT = 10 /* A/B switch for the brick sweeps of the fused WCSPH step (default brick shape): bit mask of
+    SPH_OPT_KERNEL_VARIANT = 10 /* A/B switch for the brick sweeps of the fused WCSPH step: bit mask of
                                   SPH_VAR_* below.  Every combination computes the same sums (list order and rounding
                                   apart); -1 = the library's default */
 };
-#define SPH_VAR_PAD 1      /* candidate filter in whole groups of 8 (reads past a run's end masked off), no one-at-a-time tail */
-#define SPH_VAR_2PHASE 2   /* density: pair terms in a second loop over the lane's own list instead of inside the emission loop */
-#define SPH_VAR_MICRO 4    /* emission loop: constants in VGPRs, range-checked buffer stores (no branch, no 64-bit address) */
+#define SPH_VAR_GROUPS 1   /* density: all nine runs filtered first (masks in registers), hits emitted centre run / edge runs / corner
+                              runs, each group by descending hit count */
+#define SPH_VAR_RING 2     /* density: hit masks to a per-lane LDS ring, ONE balanced emission loop per lane (measured: no gain
+                              over GROUPS with compiler-generated code, profiles/r03f_variants_partition_x_emission.json) */
 #define SPH_VAR_FORCE_BF 8 /* force sweep: branch-free fluid pair term, buffer addressing for list and gather */
 #define SPH_VAR_DEEP 16    /* list-reading sweeps: list entries loaded a whole round (3 pairs) before they are decoded */
-#define SPH_VAR_MIRROR 32  /* density (with PAD | MICRO): all nine runs filtered first, hits emitted near side first */
-#define SPH_VAR_SORTED 64  /* with MIRROR: every lane emits its runs in order of descending hit count instead */
-#define SPH_VAR_GROUPS 128 /* with MIRROR: centre run, then the edge runs and the corner runs each by descending hit count */
-#define SPH_VAR_RING 256   /* density (with PAD | MICRO): hit masks to a per-lane LDS ring, ONE balanced emission loop per lane */
+/* 0 = the baseline: run-by-run emission in the reference's (dx, dy) order, plain list loop in the force sweep.
+ * Default = GROUPS | FORCE_BF | DEEP.  (Rounds 1-2 also carried PAD, MICRO -- now always on -- and 2PHASE, MIRROR,
+ * SORTED: measured, superseded and removed; their tables are profiles/r02c, r02o, r02p.) */
 
 /* ms accumulated by sph_step since the last sph_reset_timings (HIP events on
  * the context's stream).  sort = K1+K2+K3 (initialize_particle_system),

@@ -806,16 +806,11 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                                                       unsigned char* __restrict__ gcnt, int cap, int list_cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool HAS_W = !mode_reads_list<MODE>();
-    constexpr bool V_PAD = (VAR & SPH_VAR_PAD) != 0;
-    constexpr bool V_2P = (VAR & SPH_VAR_2PHASE) != 0 && mode_inline_physics<MODE>();
-    constexpr bool V_MICRO = (VAR & SPH_VAR_MICRO) != 0;
-    constexpr bool V_RING = (VAR & SPH_VAR_RING) != 0 && V_PAD && V_MICRO && CFG::RD > 0 && mode_inline_physics<MODE>();
-    constexpr bool V_MIRROR = (VAR & SPH_VAR_MIRROR) != 0 && V_PAD && V_MICRO && !V_RING;
-    constexpr bool V_SORTED = (VAR & (SPH_VAR_SORTED | SPH_VAR_GROUPS)) != 0 && V_MIRROR;
-    constexpr bool V_GROUPS = (VAR & SPH_VAR_GROUPS) != 0 && V_MIRROR;
+    constexpr bool V_RING = (VAR & SPH_VAR_RING) != 0 && CFG::RD > 0 && mode_inline_physics<MODE>();
+    constexpr bool V_GROUPS = (VAR & SPH_VAR_GROUPS) != 0 && !V_RING && !mode_reads_list<MODE>();
     constexpr bool V_BF = (VAR & SPH_VAR_FORCE_BF) != 0 && MODE == GM_FORCE_FUSED_U;
     constexpr bool V_DEEP = (VAR & SPH_VAR_DEEP) != 0 && mode_reads_list<MODE>();
-    constexpr bool INLINE_PHYS = mode_inline_physics<MODE>() && !V_2P;  // pair terms inside the emission loop
+    constexpr bool INLINE_PHYS = mode_inline_physics<MODE>();  // pair terms inside the emission loop
     float4* sQ = reinterpret_cast<float4*>(smem + CFG::OFF_Q);
     float* sW = reinterpret_cast<float*>(smem + CFG::off_w(HAS_W));  // only when HAS_W
     // Shell origin.  Candidates are staged in shell-local coordinates as (-2x', -2y', -2z', |x'|^2) so the
@@ -1009,16 +1004,16 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
             const float txl_ = t.x - Ox, tyl_ = t.y - Oy, tzl_ = t.z - Oz;
             // superset filter (exact r < h test in phase 2): r2 - |x_i'|^2 < h^2 (1 + 2e-4) - |x_i'|^2
             const float thr = d.h * d.h * 1.0002f - (txl_ * txl_ + tyl_ * tyl_ + tzl_ * tzl_);
-            unsigned short* const gl = glist + gi;  // row k of this target's list: gl[k * cap]
-            // V_MICRO: the list rows through a raw buffer whose size is LISTCAP rows -- a store into row >= LISTCAP is
-            // dropped by the hardware range check (no compare, no branch), the byte offset is one 32-bit VGPR
+            // The list rows go through a raw buffer whose size is LISTCAP rows -- a store into row >= LISTCAP is dropped
+            // by the hardware range check (no compare, no branch), the byte offset is one 32-bit VGPR -- and the
+            // constants of the pair term sit in VGPRs (an SGPR source halves a VALU instruction's issue rate).
             const __amdgpu_buffer_rsrc_t lrs = sph_rsrc(glist, (unsigned)CFG::LISTCAP * (unsigned)cap * 2u);
             unsigned voff = (unsigned)gi * 2u;
-            const unsigned vcap2 = V_MICRO ? sph_in_vgpr((unsigned)cap * 2u) : 0u;
-            const float v_inv_h = V_MICRO ? sph_in_vgpr(d.inv_h) : d.inv_h, v_kw = V_MICRO ? sph_in_vgpr(d.k_w) : d.k_w;
-            const float v_kw2 = V_MICRO ? sph_in_vgpr(d.k_w * 2.0f) : d.k_w * 2.0f;
-            const float v_kw8 = V_MICRO ? sph_in_vgpr(d.k_w * 8.0f) : d.k_w * 8.0f;
-            (void)gl; (void)lrs; (void)voff; (void)vcap2; (void)v_inv_h; (void)v_kw; (void)v_kw2; (void)v_kw8;
+            const unsigned vcap2 = sph_in_vgpr((unsigned)cap * 2u);
+            const float v_inv_h = sph_in_vgpr(d.inv_h);
+            const float v_kw2 = sph_in_vgpr(d.k_w * 2.0f);
+            const float v_kw8 = sph_in_vgpr(d.k_w * 8.0f);
+            (void)lrs; (void)voff; (void)vcap2; (void)v_inv_h; (void)v_kw2; (void)v_kw8;
 // Hits are collected in a per-run bitmask register (no LDS traffic while filtering) and turned into list
 // entries once per chunk of <= 32 candidates: ~7 ds_write per run instead of one per candidate.
 // One candidate = 3 FMA + 1 add + 1 v_alignbit: the test value r2' - thr' is negative for a hit, and alignbit shifts
@@ -1028,18 +1023,11 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
             // hit mask of the n <= 32 candidates from LDS slot `base` on (n >= 1)
             auto filter_chunk = [&](int base, int n) -> unsigned {
                 unsigned mask = 0;
-                // V_PAD: whole groups of 8 only.  Up to 7 records past the run's end are tested too (they are
+                // Whole groups of 8 only.  Up to 7 records past the run's end are tested too (they are
                 // the next run's, or the first bytes of the m_V array behind the last record: always inside
                 // this workgroup's LDS) and their bits are cleared afterwards -- 7 wasted tests at 5 VALU each
                 // instead of up to 7 one-candidate trips that each wait for their own ds_read.
-                int k = V_PAD ? ((n + 7) & ~7) : n;
-                if (!V_PAD) {
-                    while (k & 7) {  // the ragged end first
-                        --k;
-                        const float4 q0 = sQ[base + k];
-                        SPH_ACC(q0);
-                    }
-                }
+                int k = (n + 7) & ~7;
                 while (k > 0) {
                     k -= 8;
                     const float4* q = &sQ[base + k];
@@ -1048,7 +1036,7 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                     SPH_ACC(q7); SPH_ACC(q6); SPH_ACC(q5); SPH_ACC(q4);
                     SPH_ACC(q3); SPH_ACC(q2); SPH_ACC(q1); SPH_ACC(q0);
                 }
-                if (V_PAD) mask &= 0xffffffffu >> (32 - n);
+                mask &= 0xffffffffu >> (32 - n);
                 if (d.ablate & 16) mask &= (d.ablate >> 8);  // profiling: filter only (mask kept live, no hit emitted)
                 return mask;
             };
@@ -1071,7 +1059,7 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                 const float w = v_kw2 * (tq * tq * tq) - v_kw8 * (uq * uq * uq);
                 t.s0 += mVj * w;
             };
-            // V_MICRO: the hits of one mask become list entries `tagbase + bit` and (inline sweeps) density terms
+            // the hits of one mask become list entries `tagbase + bit` and (inline sweeps) density terms
             auto emit_micro = [&](unsigned mask, unsigned tagbase, unsigned base16) {
                 cnt += __popc(mask);
                 while (mask) {
@@ -1150,13 +1138,12 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                     }
                 }
             } else
-            if (V_MIRROR) {
-                // SPH_VAR_MIRROR: filter all nine runs first (their first 32 candidates: one mask and one tag|base per
-                // run stay in registers; longer runs emit their further chunks at once), then emit NEAR SIDE FIRST:
-                // a target in the upper half of its cell along x walks dx = +1, 0, -1 instead of -1, 0, +1, likewise
-                // y.  A lane's hits sit mostly in the runs on its near side, so in the natural order lanes of
-                // opposite halves make every run's loop as long as the busier half needs; mirrored, the lanes of a
-                // wave are busy in the same phases (tools/emission_model.py: 109 -> 81 trips per wave in a settled flow).
+            if (V_GROUPS) {
+                // SPH_VAR_GROUPS (default): all nine runs are filtered first (their first 32 candidates: one mask and
+                // one tag|base per run stay in registers; longer runs emit their further chunks at once), then every
+                // lane emits its runs by descending hit count within three groups -- the centre run (it always holds the
+                // most hits), the four edge runs, the four corner runs: phase p then costs the wave about the p-th
+                // largest count of its busiest lane (tools/emission_model.py: 109 -> ~69 trips per wave in a settled flow).
                 unsigned mk[9], tk[9];
 #pragma unroll
                 for (int r = 0; r < 9; ++r) {
@@ -1179,51 +1166,20 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                     for (int base = lo + 32; base < hi; base += 32)
                         emit_micro(filter_chunk(base, min(32, hi - base)), ((unsigned)ncol << 11) | (unsigned)base, (unsigned)base << 4);
                 }
-                if (V_SORTED) {
-                    // SPH_VAR_SORTED: every lane emits its runs in order of descending hit count (a 25-exchange sorting
-                    // network on the nine words (hits << 16 | tag|base), the mask travels with its word): phase p then
-                    // costs the wave the p-th largest count of its busiest lane -- the bound for any per-lane order
-                    // (tools/emission_model.py: 64 -> 51 trips at rest, 81 -> 65 settled).
 #pragma unroll
-                    for (int r = 0; r < 9; ++r) tk[r] |= (unsigned)__popc(mk[r]) << 16;
+                for (int r = 0; r < 9; ++r) tk[r] |= (unsigned)__popc(mk[r]) << 16;
+                // ten compare-exchanges on the words (hits << 16 | tag|base), the mask travelling with its word
 #define SPH_CE(A_, B_) { const bool sw_ = tk[A_] < tk[B_]; const unsigned ta_ = tk[A_], ma_ = mk[A_]; \
                          tk[A_] = sw_ ? tk[B_] : ta_; mk[A_] = sw_ ? mk[B_] : ma_; tk[B_] = sw_ ? ta_ : tk[B_]; mk[B_] = sw_ ? ma_ : mk[B_]; }
-                    if (V_GROUPS) {
-                        // SPH_VAR_GROUPS: the centre run first (it always holds the most hits), then the four edge runs and
-                        // the four corner runs each in descending order: ten exchanges instead of twenty-five
-                        SPH_CE(1, 3) SPH_CE(5, 7) SPH_CE(1, 5) SPH_CE(3, 7) SPH_CE(3, 5)
-                        SPH_CE(0, 2) SPH_CE(6, 8) SPH_CE(0, 6) SPH_CE(2, 8) SPH_CE(2, 6)
-                    } else {
-                    SPH_CE(0, 3) SPH_CE(1, 7) SPH_CE(2, 5) SPH_CE(4, 8)
-                    SPH_CE(0, 7) SPH_CE(2, 4) SPH_CE(3, 8) SPH_CE(5, 6)
-                    SPH_CE(0, 2) SPH_CE(1, 3) SPH_CE(4, 5) SPH_CE(7, 8)
-                    SPH_CE(1, 4) SPH_CE(3, 6) SPH_CE(5, 7)
-                    SPH_CE(0, 1) SPH_CE(2, 4) SPH_CE(3, 5) SPH_CE(6, 8)
-                    SPH_CE(2, 3) SPH_CE(4, 5) SPH_CE(6, 7)
-                    SPH_CE(1, 2) SPH_CE(3, 4) SPH_CE(5, 6)
-                    }
+                SPH_CE(1, 3) SPH_CE(5, 7) SPH_CE(1, 5) SPH_CE(3, 7) SPH_CE(3, 5)
+                SPH_CE(0, 2) SPH_CE(6, 8) SPH_CE(0, 6) SPH_CE(2, 8) SPH_CE(2, 6)
 #undef SPH_CE
-                    if (V_GROUPS) {
-                        constexpr int order[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
+                constexpr int order[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
 #pragma unroll
-                        for (int p = 0; p < 9; ++p) emit_micro(mk[order[p]], tk[order[p]] & 0xffffu, (tk[order[p]] & 2047u) << 4);
-                    } else
-#pragma unroll
-                    for (int p = 0; p < 9; ++p) emit_micro(mk[p], tk[p] & 0xffffu, (tk[p] & 2047u) << 4);
-                } else {
-                const float half = 0.5f * d.grid_size;
-                const bool sxh = txl_ - (float)(ix - sx0) * d.grid_size >= half, syh = tyl_ - (float)(iy - sy0) * d.grid_size >= half;
-#pragma unroll
-                for (int p = 0; p < 9; ++p) {
-                    const int px = p / 3, py = p % 3;
-                    const int ra = px * 3 + py, rb = (2 - px) * 3 + py, rc = px * 3 + (2 - py), rd = (2 - px) * 3 + (2 - py);
-                    const unsigned m_ = syh ? (sxh ? mk[rd] : mk[rc]) : (sxh ? mk[rb] : mk[ra]);
-                    const unsigned t_ = syh ? (sxh ? tk[rd] : tk[rc]) : (sxh ? tk[rb] : tk[ra]);
-                    emit_micro(m_, t_, (t_ & 2047u) << 4);
-                }
-                }
+                for (int p = 0; p < 9; ++p) emit_micro(mk[order[p]], tk[order[p]] & 0xffffu, (tk[order[p]] & 2047u) << 4);
             } else
-            // phase 1: filter the 9 column runs into the private index list (4 LDS slots in flight)
+            // baseline (variant 0; also what the stand-alone filtering sweeps run): run by run in the reference's
+            // (dx, dy) order, every chunk emitted as soon as it is filtered
             for (int dx = -1; dx <= 1; ++dx) {
                 const int nx = ix + dx;
                 if (nx < 0 || nx >= d.nx) continue;
@@ -1234,39 +1190,8 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                     const int rel = -sColG[ncol];
                     const int lo = sCE[ncol * CFG::NZS + klo] + rel;
                     const int hi = sCE[ncol * CFG::NZS + khi + 1] + rel;
-                    const unsigned tag = (unsigned)ncol << 11;
-                    for (int base = lo; base < hi; base += 32) {
-                        const int n = min(32, hi - base);
-                        unsigned mask = filter_chunk(base, n);
-                        const unsigned tagbase = tag | (unsigned)base;
-                        if (V_MICRO) {
-                            emit_micro(mask, tagbase, (unsigned)base << 4);
-                        } else
-                        while (mask) {  // rows coalesce across the wave's lanes (consecutive gi)
-                            const unsigned bit = (unsigned)__ffs((int)mask) - 1u;
-                            mask &= mask - 1u;
-                            if (cnt < CFG::LISTCAP && !(d.ablate & 2)) gl[(size_t)cnt * cap] = (unsigned short)(tagbase + bit);
-                            ++cnt;
-                            if (INLINE_PHYS && !(d.ablate & 32)) {
-                                // The density pair term is cheap: do it here instead of re-reading the list, and
-                                // branch-free: (1-q) is clamped at 0, so W vanishes for r >= h exactly as if the
-                                // pair had been rejected (particle_system.py:385); the self pair (r = 0) supplies
-                                // the m_V_i W(0) term of WCSPH.py:39.
-                                const int j = base + (int)bit;
-                                const float4 q4 = sQ[j];
-                                const float rx = fmaf(0.5f, q4.x, txl_), ry = fmaf(0.5f, q4.y, tyl_), rz = fmaf(0.5f, q4.z, tzl_);
-                                const float r2 = rx * rx + ry * ry + rz * rz;
-                                const float qn = r2 * sph_rsq(r2) * d.inv_h;
-                                const float tq = fmaxf(1.0f - qn, 0.0f);
-                                const float inner = d.k_w * ((6.0f * qn - 6.0f) * qn * qn + 1.0f);
-                                const float outer = d.k_w * 2.0f * (tq * tq * tq);
-                                // (m_V through an explicit 32-bit LDS byte offset: derived from &sQ[j] the compiler
-                                // emits a 64-bit multiply-add for this address)
-                                const float mVj = *reinterpret_cast<const float*>(smem + CFG::off_w(true) + (j << 2));
-                                t.s0 += mVj * (qn <= 0.5f ? inner : outer);
-                            }
-                        }
-                    }
+                    for (int base = lo; base < hi; base += 32)
+                        emit_micro(filter_chunk(base, min(32, hi - base)), ((unsigned)ncol << 11) | (unsigned)base, (unsigned)base << 4);
                 }
             }
             // list overflow (extreme compression): the list-reading sweep must take the exact slow path; this
@@ -1284,41 +1209,6 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
             if (cnt >= SPH_CNT_LIST_OVF) { walk = true; cnt = 0; }
         }
         if (mode_writes_list<MODE>() && g && overflow) gcnt[gi] = (unsigned char)SPH_CNT_WALK;
-        if (V_2P && g && !walk && !overflow && !(d.ablate & 1)) {
-            // V_2P, phase 2 of the density sweep: ONE loop over the lane's own list.  Its trip count is the wave's
-            // longest list (33 on a rest lattice, ~46 in a settled flow) where the inline form pays the sum over the
-            // nine runs of the wave's per-run maxima (70 / ~110, tools/emission_model.py).  Row k of all 64 lanes is
-            // one 128-byte line just written by this wave (L2-resident); four rows are in flight ahead of the physics.
-            const float txl_ = t.x - Ox, tyl_ = t.y - Oy, tzl_ = t.z - Oz;
-            const float v_inv_h = V_MICRO ? sph_in_vgpr(d.inv_h) : d.inv_h, v_kw = V_MICRO ? sph_in_vgpr(d.k_w) : d.k_w;
-            const float v_kw2 = V_MICRO ? sph_in_vgpr(d.k_w * 2.0f) : d.k_w * 2.0f;
-            const __amdgpu_buffer_rsrc_t lrs2 = sph_rsrc(glist, (unsigned)SPH_GLIST_ROWS * (unsigned)cap * 2u);
-            const unsigned cap2 = (unsigned)cap * 2u;
-            const int vg = gi * 2;
-            auto lde = [&](int row) -> unsigned {  // (row is wave-uniform: the row offset is a scalar; glc: past this CU's L1)
-                return (unsigned)__builtin_amdgcn_raw_buffer_load_b16(lrs2, vg, (int)((unsigned)min(row, CFG::LISTCAP - 1) * cap2), 1);
-            };
-            auto dens_one = [&](unsigned e, bool live) {
-                const unsigned aq = (e << 4) & 0x7ff0u;  // LDS byte offset of the record (slot = low 11 bits of the entry)
-                const float4 q4 = *reinterpret_cast<const float4*>(smem + CFG::OFF_Q + aq);
-                const float mVj = *reinterpret_cast<const float*>(smem + CFG::off_w(true) + (aq >> 2));
-                const float rx = fmaf(0.5f, q4.x, txl_), ry = fmaf(0.5f, q4.y, tyl_), rz = fmaf(0.5f, q4.z, tzl_);
-                const float r2 = rx * rx + ry * ry + rz * rz;
-                const float qn = r2 * __builtin_amdgcn_rsqf(r2 + 1e-30f) * v_inv_h;
-                const float tq = fminf(fmaxf(1.0f - qn, 0.0f), 1.0f);
-                const float inner = v_kw * ((6.0f * qn - 6.0f) * qn * qn + 1.0f);
-                const float outer = v_kw2 * (tq * tq * tq);
-                const float w = mVj * (qn <= 0.5f ? inner : outer);
-                t.s0 += live ? w : 0.0f;
-            };
-            unsigned e0 = lde(0), e1 = lde(1), e2 = lde(2), e3 = lde(3);
-            for (int k = 0; k < cnt; k += 4) {
-                const unsigned c0 = e0, c1 = e1, c2 = e2, c3 = e3;
-                e0 = lde(k + 4); e1 = lde(k + 5); e2 = lde(k + 6); e3 = lde(k + 7);
-                dens_one(c0, true); dens_one(c1, k + 1 < cnt); dens_one(c2, k + 2 < cnt); dens_one(c3, k + 3 < cnt);
-            }
-            t.self_in_sum = key_i != 0;  // the self pair is a list entry (W(0) term of WCSPH.py:39), except in flat cell 0
-        }
         if (g && !walk && !(d.ablate & 1) && !mode_inline_physics<MODE>()) {
             // phase 2: pair physics over the list.  Register sets rotate: while pair k is computed from one, the
             // records of the next entries are in flight into the others.  Every fetch is UNCONDITIONAL (past the end it re-reads
@@ -1566,29 +1456,20 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
     return 0;
 }
 
+// The brick sweeps address their list rows with 32-bit byte offsets (SPH_VOFF_ROWS) and k_brick_list keeps per-layer
+// arrays in LDS (SPH_BRICK_MAX_NZ): contexts beyond either limit (> 20.6 M particles of capacity, > 1000 cell layers in
+// z) take the per-particle cell walk.
+static bool brick_ok(const SphContext* c) {
+    return (unsigned long long)c->cap * 2ull * SPH_VOFF_ROWS < (1ull << 32) && c->p.grid_num[2] <= SPH_BRICK_MAX_NZ;
+}
+
 template <int MODE>
 static int launch_brick(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, int hi2 = 0) {
-    // SPH_OPT_KERNEL_VARIANT: A/B instances of the two sweeps of the fused WCSPH step (default brick shape only).
-    // The buffer-addressed variants hold byte offsets in 32 bits (SPH_VOFF_ROWS).
-    int var = c->opt_variant;
-    if ((unsigned long long)c->cap * 2ull * SPH_VOFF_ROWS >= (1ull << 32)) var &= SPH_VAR_PAD;
+    // SPH_OPT_KERNEL_VARIANT: the instances of the two sweeps of the fused WCSPH step (include/sph_hip.h)
+    const int var = c->opt_variant;
     if constexpr (MODE == GM_DENSITY_EOS) {
-        if ((var & SPH_VAR_RING) && (var & 7) == 5) return launch_brick_cfg<MODE, CfgR, SPH_VAR_RING | 5>(c, lo, hi, lo2, hi2);
-        switch ((var & SPH_VAR_MIRROR) && (var & 7) == 5 ? 0 : (var & 7)) {
-            case 1: return launch_brick_cfg<MODE, Cfg0, 1>(c, lo, hi, lo2, hi2);
-            case 2: return launch_brick_cfg<MODE, Cfg0, 2>(c, lo, hi, lo2, hi2);
-            case 3: return launch_brick_cfg<MODE, Cfg0, 3>(c, lo, hi, lo2, hi2);
-            case 4: return launch_brick_cfg<MODE, Cfg0, 4>(c, lo, hi, lo2, hi2);
-            case 5: return launch_brick_cfg<MODE, Cfg0, 5>(c, lo, hi, lo2, hi2);
-            case 6: return launch_brick_cfg<MODE, Cfg0, 6>(c, lo, hi, lo2, hi2);
-            case 7: return launch_brick_cfg<MODE, Cfg0, 7>(c, lo, hi, lo2, hi2);
-            default: break;
-        }
-        if ((var & (SPH_VAR_MIRROR | 7)) == (SPH_VAR_MIRROR | 5)) {
-            if (var & SPH_VAR_GROUPS) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS | SPH_VAR_MIRROR | 5>(c, lo, hi, lo2, hi2);
-            if (var & SPH_VAR_SORTED) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_SORTED | SPH_VAR_MIRROR | 5>(c, lo, hi, lo2, hi2);
-            return launch_brick_cfg<MODE, Cfg0, SPH_VAR_MIRROR | 5>(c, lo, hi, lo2, hi2);
-        }
+        if (var & SPH_VAR_RING) return launch_brick_cfg<MODE, CfgR, SPH_VAR_RING>(c, lo, hi, lo2, hi2);
+        if (var & SPH_VAR_GROUPS) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS>(c, lo, hi, lo2, hi2);
     }
     if constexpr (MODE == GM_FORCE_FUSED_U) {
         switch (var & (SPH_VAR_FORCE_BF | SPH_VAR_DEEP)) {
@@ -1607,7 +1488,7 @@ static int launch_brick(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, in
 // force sweep over the targets of x layers [lo, hi) only (slab mode: boundary layers first, interior later)
 int sphk_gather_layers(SphContext* c, int mode, int lo, int hi, int lo2, int hi2) {
     if (c->N <= 0 || (hi <= lo && hi2 <= lo2)) return 0;
-    if (mode != GM_FORCE_FUSED || c->opt_gather_impl == 0 || c->p.grid_num[2] > SPH_BRICK_MAX_NZ) return sph_fail(c, SPH_E_INVALID, "layer-restricted sweeps need the brick force kernel");
+    if (mode != GM_FORCE_FUSED || c->opt_gather_impl == 0 || !brick_ok(c)) return sph_fail(c, SPH_E_INVALID, "layer-restricted sweeps need the brick force kernel");
     if (hi < lo) hi = lo;
     if (c->uniform_state == 1 && c->lists_valid && c->stg_kind == 1) return launch_brick<GM_FORCE_FUSED_U>(c, lo, hi, lo2, hi2);
     return launch_brick<GM_FORCE_FUSED>(c, lo, hi, lo2, hi2);
@@ -1616,7 +1497,7 @@ int sphk_gather_layers(SphContext* c, int mode, int lo, int hi, int lo2, int hi2
 template <int MODE>
 static int launch_sweep(SphContext* c) {
     if (c->N <= 0) return 0;
-    if (c->opt_gather_impl == 0 || c->p.grid_num[2] > SPH_BRICK_MAX_NZ) return launch_simple<MODE>(c, nullptr, c->N);
+    if (c->opt_gather_impl == 0 || !brick_ok(c)) return launch_simple<MODE>(c, nullptr, c->N);
     int rc = launch_brick<MODE>(c);
     if (!rc && mode_writes_list<MODE>()) { c->lists_valid = true; c->gcnt_written = true; }
     if (!rc && MODE == GM_DENSITY_EOS) { c->stg_kind = c->uniform_state == 1 ? 1 : 0; if (c->stg_kind == 1) c->aux_stale = true; }
@@ -1629,19 +1510,16 @@ static int launch_sweep(SphContext* c) {
 template <int MODE>
 static int launch_df(SphContext* c) {
     if (c->N <= 0) return 0;
-    if (c->opt_gather_impl == 0 || c->p.grid_num[2] > SPH_BRICK_MAX_NZ || (mode_reads_list<MODE>() && !c->lists_valid)) {
+    if (c->opt_gather_impl == 0 || !brick_ok(c) || (mode_reads_list<MODE>() && !c->lists_valid)) {
         if (mode_is_df_vdiv<MODE>()) c->k_kind = 0;  // density_adv changes, the walk does not refresh k_j
         return launch_simple<MODE>(c, nullptr, c->N);
     }
-    // SPH_OPT_KERNEL_VARIANT: the list-writing density sweep takes the padded filter + arranged emission loop (buffer
-    // offsets are 32-bit: see launch_brick).  The early entry loads of SPH_VAR_DEEP do nothing for these sweeps
-    // (DFSPH step 3.46 vs 3.51 ms with them, profiles/r02g): their pair terms gather 4 bytes, not a 16-byte record.
-    int var = c->opt_variant;
-    if ((unsigned long long)c->cap * 2ull * SPH_VOFF_ROWS >= (1ull << 32)) var &= SPH_VAR_PAD;
+    // SPH_OPT_KERNEL_VARIANT: the list-writing density sweep can take the ring emission; the group-sorted emission and
+    // the early entry loads of SPH_VAR_DEEP do nothing measurable for these sweeps (DFSPH step 3.46 vs 3.51 ms with
+    // DEEP, profiles/r02g: their pair terms gather 4 bytes, not a 16-byte record).
     int rc;
     if constexpr (mode_writes_list<MODE>()) {
-        if ((var & (SPH_VAR_RING | 7)) == (SPH_VAR_RING | 5)) rc = launch_brick_cfg<MODE, CfgR, SPH_VAR_RING | SPH_VAR_PAD | SPH_VAR_MICRO>(c);
-        else if ((var & (SPH_VAR_PAD | SPH_VAR_MICRO)) == (SPH_VAR_PAD | SPH_VAR_MICRO)) rc = launch_brick_cfg<MODE, Cfg0, SPH_VAR_PAD | SPH_VAR_MICRO>(c);
+        if (c->opt_variant & SPH_VAR_RING) rc = launch_brick_cfg<MODE, CfgR, SPH_VAR_RING>(c);
         else rc = launch_brick_cfg<MODE, Cfg0>(c);
     } else
         rc = launch_brick_cfg<MODE, Cfg0>(c);
@@ -1684,7 +1562,7 @@ static int gather_dispatch(SphContext* c, int mode) {
         case GM_FORCE_FUSED:
             // one gather per pair when every fluid particle has the same mass (and the density sweep of this step
             // left its stg / gat records): see SPH_OPT_UNIFORM_FLUID
-            if (c->uniform_state == 1 && c->opt_gather_impl == 1 && c->lists_valid && c->stg_kind == 1 && c->N > 0)
+            if (c->uniform_state == 1 && c->opt_gather_impl == 1 && brick_ok(c) && c->lists_valid && c->stg_kind == 1 && c->N > 0)
                 return launch_brick<GM_FORCE_FUSED_U>(c);
             return launch_sweep<GM_FORCE_FUSED>(c);
         case GM_DF_DENSITY: return launch_df<GM_DF_DENSITY>(c);

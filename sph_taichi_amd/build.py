@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 SOURCES = ["sph_api.hip", "sph_sort.hip", "sph_gather.hip", "sph_integrate.hip", "sph_comm.hip"]
-HEADERS = [os.path.join(CSRC, "sph_internal.h"), os.path.join(_HERE, "..", "include", "sph_hip.h")]
+HEADERS = [os.path.join(CSRC, "sph_internal.h"), os.path.join(CSRC, "sph_bricks.h"), os.path.join(_HERE, "..", "include", "sph_hip.h")]
 LIB = os.path.join(_HERE, "libsph_hip.so")
 # -fno-slp-vectorize: the SLP pass packs the x/y lanes of the distance test into v_pk_*_f32, which on gfx950
 # costs extra v_mov + s_nop per pair test (measured: slower than plain v_sub/v_fma)

@@ -22,6 +22,7 @@
 //
 // No MFMA: this is a bandwidth/VALU-bound gather, not a contraction.
 #include "sph_internal.h"
+#include "sph_bricks.h"
 
 #define TPB 256
 
@@ -681,111 +682,11 @@ template <class CFG>
 __global__ __launch_bounds__(TPB) void k_brick_list(DevView d, int nbx, int nby, int2* __restrict__ list,
                                                     int* __restrict__ count, int list_cap, int tmax, int smax, int fixed_bz) {
     extern __shared__ int sm_bl[];
-    __shared__ int s_cnt[TPB / 64][2];
-    __shared__ int s_base[2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nz = d.nz;
-    int* Sp = sm_bl + wave * 5 * (nz + 1);  // [nz + 1] shell records in layers [0, z) of the column group's shell columns
-    int* Tp = Sp + (nz + 1);                // [nz + 1] targets in layers [0, z)
-    int* Ex = Tp + (nz + 1);                // [nz] height of the brick that would start at layer z (0: no target there)
-    int* bz = Ex + (nz + 1);                // bricks of this column group: first layer | height << 16
-    int* bt = bz + (nz + 1);                //                              targets
-    const int cg = blockIdx.x * (TPB / 64) + wave;
-    const bool live = cg < nbx * nby;
-    const int bxi = cg / nby, byi = cg % nby;
-    const int cx0 = bxi * CFG::BX, cy0 = byi * CFG::BY;
-    int carryS = 0, carryT = 0;
-    if (live && lane == 0) { Sp[0] = 0; Tp[0] = 0; }
-    for (int zb = 0; zb < nz; zb += 64) {
-        const int z = zb + lane;
-        // all (BX + 2) (BY + 2) columns' loads are issued before the first is used (a loop over the columns that waits
-        // for each pair of loads made this kernel three times as long as the one-lane-per-brick kernel it replaced)
-        int hi_[CFG::NCOL], lo_[CFG::NCOL];
-#pragma unroll
-        for (int c = 0; c < CFG::NCOL; ++c) {
-            const int ix = cx0 - 1 + c / (CFG::BY + 2), iy = cy0 - 1 + c % (CFG::BY + 2);
-            const bool ok = live && z < nz && ix >= 0 && ix < d.nx && iy >= 0 && iy < d.ny;
-            const int f = ok ? sph_flatten(d, ix, iy, z) : 0;
-            hi_[c] = ok ? d.cell_end[f] : 0;
-            lo_[c] = (ok && f > 0) ? d.cell_end[f - 1] : 0;
-        }
-        int s_ = 0, t_ = 0;
-#pragma unroll
-        for (int c = 0; c < CFG::NCOL; ++c) {
-            const int ix = cx0 - 1 + c / (CFG::BY + 2), iy = cy0 - 1 + c % (CFG::BY + 2);
-            const int n = hi_[c] - lo_[c];
-            s_ += n;
-            const bool tgt = ix >= cx0 && ix < cx0 + CFG::BX && iy >= cy0 && iy < cy0 + CFG::BY &&
-                             ((ix >= d.tgt_lo && ix < d.tgt_hi) || (ix >= d.tgt_lo2 && ix < d.tgt_hi2));
-            t_ += tgt ? n : 0;
-        }
-        const int si = sph_wave_inclusive_scan(s_, lane), ti = sph_wave_inclusive_scan(t_, lane);
-        if (live && z < nz) { Sp[z + 1] = carryS + si; Tp[z + 1] = carryT + ti; }
-        carryS += __shfl(si, 63, 64);
-        carryT += __shfl(ti, 63, 64);
-    }
-    __syncthreads();
-    // every layer: how high would a brick starting here be?
-    if (live)
-        for (int z = lane; z < nz; z += 64) {
-            int e = 0;
-            const int t0 = Tp[z];
-            if (Tp[z + 1] != t0) {
-                if (fixed_bz > 0) {
-                    e = min(fixed_bz - z % fixed_bz, nz - z);
-                } else {
-                    const int s0 = Sp[max(z - 1, 0)];
-                    e = 1;
-                    while (z + e < nz && e < CFG::BZ && Tp[z + e + 1] != Tp[z + e] && Tp[z + e + 1] - t0 <= tmax &&
-                           Sp[min(z + e + 2, nz)] - s0 <= smax)
-                        ++e;
-                }
-            }
-            Ex[z] = e;
-        }
-    __syncthreads();
-    int nb = 0;
-    if (live && lane == 0) {
-        int z = 0;
-        while (z < nz) {
-            const int e = Ex[z];
-            if (e == 0) { ++z; continue; }
-            const int z0 = fixed_bz > 0 ? (z / fixed_bz) * fixed_bz : z;  // fixed partition: bricks aligned to multiples of fixed_bz
-            const int z1 = z + e;
-            bz[nb] = z0 | ((z1 - z0) << 16);
-            bt[nb] = Tp[z1] - Tp[z0];
-            ++nb;
-            z = z1;
-        }
-    }
-    nb = __shfl(nb, 0, 64);
-    int nh = 0;
-    for (int k0 = 0; k0 < nb; k0 += 64) {
-        const int k = k0 + lane;
-        nh += __popcll(__ballot(k < nb && bt[k] >= SPH_BRICK_HEAVY));  // (lane 0's LDS writes: same wave, program order)
-    }
-    if (lane == 0) { s_cnt[wave][0] = nh; s_cnt[wave][1] = nb - nh; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int th = 0, tl = 0;
-        for (int w = 0; w < TPB / 64; ++w) { th += s_cnt[w][0]; tl += s_cnt[w][1]; }
-        s_base[0] = th ? atomicAdd(&count[0], th) : 0;
-        s_base[1] = tl ? atomicAdd(&count[1], tl) : 0;
-    }
-    __syncthreads();
-    int oh = s_base[0], ol = s_base[1];
-    for (int w = 0; w < wave; ++w) { oh += s_cnt[w][0]; ol += s_cnt[w][1]; }
-    const unsigned long long below = (1ull << lane) - 1ull;
-    for (int k0 = 0; k0 < nb; k0 += 64) {
-        const int k = k0 + lane;
-        const bool ok = k < nb;
-        const bool heavy = ok && bt[k] >= SPH_BRICK_HEAVY, light = ok && !heavy;
-        const unsigned long long mh = __ballot(heavy), ml = __ballot(light);
-        if (heavy) list[oh + __popcll(mh & below)] = make_int2(cg, bz[k]);
-        if (light) list[list_cap - 1 - (ol + __popcll(ml & below))] = make_int2(cg, bz[k]);
-        oh += __popcll(mh);
-        ol += __popcll(ml);
-    }
+    static_assert(CFG::BX == SPH_BRICK_BX && CFG::BY == SPH_BRICK_BY && CFG::BZ == SPH_BRICK_BZ, "one footprint: the sort's scatter kernel builds the same lists");
+    BrickView bv;
+    bv.nx = d.nx; bv.ny = d.ny; bv.nz = d.nz; bv.tgt_lo = d.tgt_lo; bv.tgt_hi = d.tgt_hi; bv.tgt_lo2 = d.tgt_lo2; bv.tgt_hi2 = d.tgt_hi2;
+    bv.cell_end = d.cell_end;
+    sph_brick_list_block<CFG::BX, CFG::BY, CFG::BZ>(bv, nbx, nby, list, count, list_cap, tmax, smax, fixed_bz, (int)blockIdx.x, sm_bl);
 }
 
 // a uniform value held in a VGPR: on gfx950 a VALU instruction with an SGPR source issues at half rate
@@ -1401,6 +1302,43 @@ static int launch_simple(SphContext* c, const int* list, int n) {
     return 0;
 }
 
+// The brick sweeps address their list rows with 32-bit byte offsets (SPH_VOFF_ROWS) and k_brick_list keeps per-layer
+// arrays in LDS (SPH_BRICK_MAX_NZ): contexts beyond either limit (> 20.6 M particles of capacity, > 1000 cell layers in
+// z) take the per-particle cell walk.
+static bool brick_ok(const SphContext* c) {
+    return (unsigned long long)c->cap * 2ull * SPH_VOFF_ROWS < (1ull << 32) && c->p.grid_num[2] <= SPH_BRICK_MAX_NZ;
+}
+
+// identity of a partition: footprint, cut rule, limits (the target ranges complete the key)
+static int brick_partition_id(const SphContext* c) {
+    const int fixed_bz = c->opt_brick_shape == 1 ? SPH_BRICK_BZ : 0;
+    return ((SPH_BRICK_BX * 10 + SPH_BRICK_BY) * 10 + SPH_BRICK_BZ) * 4096 + fixed_bz * 2048 + brick_smax(c);
+}
+
+// The list for the step's default sweeps (targets = the density layers), to be built by the sort's place kernel in
+// extra workgroups: fills `a` (nblocks = 0 if the brick sweeps will not run) and records the key; the caller marks the
+// cache valid once the sort has been enqueued.
+int sphk_brick_list_prepare(SphContext* c, BrickListArgs* a) {
+    memset(a, 0, sizeof(*a));
+    if (c->N <= 0 || c->opt_gather_impl != 1 || !brick_ok(c)) return 0;
+    DevView d = sph_view(c);
+    d.tgt_lo = c->tgt_layers[0]; d.tgt_hi = c->tgt_layers[1]; d.tgt_lo2 = d.tgt_hi2 = 0;
+    if (d.tgt_hi <= d.tgt_lo) return 0;
+    const int nbx = (d.nx + SPH_BRICK_BX - 1) / SPH_BRICK_BX, nby = (d.ny + SPH_BRICK_BY - 1) / SPH_BRICK_BY;
+    if (nbx * nby * d.nz > c->brick_cap) return 0;
+    a->d.nx = d.nx; a->d.ny = d.ny; a->d.nz = d.nz;
+    a->d.tgt_lo = d.tgt_lo; a->d.tgt_hi = d.tgt_hi; a->d.tgt_lo2 = 0; a->d.tgt_hi2 = 0;
+    a->d.cell_end = d.cell_end;
+    a->nbx = nbx; a->nby = nby;
+    a->list = c->brick_list; a->count = c->brick_count; a->list_cap = c->brick_cap;
+    a->tmax = TPB; a->smax = brick_smax(c); a->fixed_bz = c->opt_brick_shape == 1 ? SPH_BRICK_BZ : 0;
+    a->nblocks = (nbx * nby + TPB / 64 - 1) / (TPB / 64);
+    a->lds_bytes = (unsigned)((TPB / 64) * 5 * (d.nz + 1) * sizeof(int));
+    const int key[5] = {brick_partition_id(c), d.tgt_lo, d.tgt_hi, 0, 0};
+    memcpy(c->bricks_key, key, sizeof(key));
+    return 0;
+}
+
 template <int MODE, class CFG, int VAR = 0>
 static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, int hi2 = 0) {
     DevView d = sph_view(c);
@@ -1430,7 +1368,7 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
     // another wrote (list entries are brick-relative).
     const int fixed_bz = c->opt_brick_shape == 1 ? CFG::BZ : 0;
     const int tmax = TPB, smax = brick_smax(c);
-    const int key[5] = {((CFG::BX * 10 + CFG::BY) * 10 + CFG::BZ) * 4096 + fixed_bz * 2048 + smax, d.tgt_lo, d.tgt_hi, d.tgt_lo2, d.tgt_hi2};
+    const int key[5] = {brick_partition_id(c), d.tgt_lo, d.tgt_hi, d.tgt_lo2, d.tgt_hi2};
     hipStream_t st = sph_stream(c);
     int2* blist = c->use_side ? c->brick_list2 : c->brick_list;
     int* bcount = c->use_side ? c->brick_count2 : c->brick_count;
@@ -1454,13 +1392,6 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
                        c->gcnt, c->cap, c->brick_cap);
     SPH_LAUNCH_CHECK(c);
     return 0;
-}
-
-// The brick sweeps address their list rows with 32-bit byte offsets (SPH_VOFF_ROWS) and k_brick_list keeps per-layer
-// arrays in LDS (SPH_BRICK_MAX_NZ): contexts beyond either limit (> 20.6 M particles of capacity, > 1000 cell layers in
-// z) take the per-particle cell walk.
-static bool brick_ok(const SphContext* c) {
-    return (unsigned long long)c->cap * 2ull * SPH_VOFF_ROWS < (1ull << 32) && c->p.grid_num[2] <= SPH_BRICK_MAX_NZ;
 }
 
 template <int MODE>

@@ -105,7 +105,7 @@ struct SphContext {
     int* cell_end;     // [G+1] the CURRENT cell array (one of cell_buf[])
     int* cell_buf[2];  // two cell arrays: while one serves the sweeps, the scatter zeroes the other for the next histogram
     int cell_cur;
-    bool brick_count_zero;  // brick_count was zeroed by the scatter (the first brick-list build of a step needs no memset)
+    bool brick_count_zero;  // brick_count is zero (set by the hash kernel) and no list has been built into it since
     bool next_cells_zero;  // cell_buf[cell_cur ^ 1] is all zero (no memset needed before the next histogram)
     int* rank_off;     // [cap] arbitrary intra-cell offset from the histogram atomics
     int* idx_unstable; // [cap]
@@ -186,6 +186,8 @@ int sphk_sort_scatter(SphContext* c, bool sort_acc);
 int sphk_rigid_partial16(SphContext* c, int object_id, int first, int count, double* out);
 int sphk_rigid_apply16(SphContext* c, int object_id, const double* sums, int mode);
 int sphk_scatter_rest(SphContext* c, const int* pid_dev, const float* x0_dev, int n);
+struct BrickListArgs;
+int sphk_brick_list_prepare(SphContext* c, BrickListArgs* a);  // sph_gather.hip: what the sort's place kernel needs to build the step's brick list
 int sphk_gather(SphContext* c, int mode);
 int sphk_gather_layers(SphContext* c, int mode, int lo, int hi, int lo2, int hi2);  // brick sweep, targets in x layers [lo,hi) u [lo2,hi2)
 int sphk_pack_advected(SphContext* c, int first, int count, void* dst);

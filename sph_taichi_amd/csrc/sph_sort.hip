@@ -15,15 +15,17 @@
 //   stable_scatter : rank of i among its cell's members by previous index,
 //                    then move the 48-byte hot record (ping-pong, no copy-back)
 #include "sph_internal.h"
+#include "sph_bricks.h"
 
 #define TPB 256
 #define SCAN_IPT 8
 #define SCAN_TILE (TPB * SCAN_IPT)
 
 __global__ __launch_bounds__(TPB) void k_hash_histogram(DevView d, int* __restrict__ cell_cnt,
-                                                        int* __restrict__ rank_off) {
+                                                        int* __restrict__ rank_off, int* __restrict__ brick_count) {
     const int i = blockIdx.x * TPB + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    if (i == 0) brick_count[0] = brick_count[1] = 0;  // (heavy, light) of the list the place kernel builds on the new cell array
     int c = -1 - lane;  // inactive lanes get distinct sentinels
     if (i < d.N) {
         const float4 p = d.xm[i];
@@ -122,18 +124,26 @@ __global__ __launch_bounds__(TPB) void k_unstable_place(DevView d, const int* __
     idx_unstable[b + rank_off[i]] = i;
 }
 
+// + the step's brick list (sph_bricks.h) in the first bl.nblocks workgroups of the scatter: the list needs the scanned
+// cell array and nothing else; as a launch of its own its ~13 us chain of dependent phases (304 workgroups) sat on the
+// critical path, beside the 6.5 us place kernel it still stuck out by half -- beside the 33 us scatter it disappears.
 template <bool SORT_ACC>
 __global__ __launch_bounds__(TPB) void k_stable_scatter(DevView d, const int* __restrict__ idx_unstable,
                                                         float4* __restrict__ xm_out, float4* __restrict__ vf_out,
                                                         float4* __restrict__ aux_out, int* __restrict__ key_out,
                                                         float4* __restrict__ acc_out, int* __restrict__ dyn_list,
                                                         int* __restrict__ dyn_count, int4* __restrict__ zero_dst,
-                                                        int zero_n4, int* __restrict__ brick_count) {
-    const int s = blockIdx.x * TPB + threadIdx.x;
-    if (s == 0) brick_count[0] = brick_count[1] = 0;  // (heavy, light) for the first brick-list build on the new order
+                                                        int zero_n4, BrickListArgs bl) {
+    extern __shared__ int sm_bl[];
+    if ((int)blockIdx.x < bl.nblocks) {
+        sph_brick_list_block<SPH_BRICK_BX, SPH_BRICK_BY, SPH_BRICK_BZ>(bl.d, bl.nbx, bl.nby, bl.list, bl.count, bl.list_cap, bl.tmax,
+                                                                        bl.smax, bl.fixed_bz, (int)blockIdx.x, sm_bl);
+        return;
+    }
+    const int s = ((int)blockIdx.x - bl.nblocks) * TPB + threadIdx.x;
     // the OTHER cell array (the previous step's, dead by now) is zeroed here for the next histogram: 2 MB of stores in
     // a 180 MB kernel instead of a memset launch of its own (~10 us per step)
-    for (int z = s; z < zero_n4; z += gridDim.x * TPB) zero_dst[z] = make_int4(0, 0, 0, 0);
+    for (int z = s; z < zero_n4; z += ((int)gridDim.x - bl.nblocks) * TPB) zero_dst[z] = make_int4(0, 0, 0, 0);
     const bool live = s < d.N;
     const int lane = threadIdx.x & 63;
     const int i = live ? idx_unstable[s] : 0;
@@ -193,10 +203,11 @@ int sphk_hash_histogram(SphContext* c) {
     c->cell_cur ^= 1;
     c->cell_end = nxt;
     c->next_cells_zero = false;
+    c->brick_count_zero = c->N > 0;
     if (c->N > 0) {
         DevView d = sph_view(c);
         hipLaunchKernelGGL(k_hash_histogram, dim3((c->N + TPB - 1) / TPB), dim3(TPB), 0, c->stream, d, c->cell_end,
-                           c->rank_off);
+                           c->rank_off, c->brick_count);
         SPH_LAUNCH_CHECK(c);
     }
     return 0;
@@ -218,19 +229,26 @@ int sphk_sort_scatter(SphContext* c, bool sort_acc) {
     const int o = c->cur ^ 1;
     int4* zero_dst = reinterpret_cast<int4*>(c->cell_buf[c->cell_cur ^ 1]);
     const int zero_n4 = c->scan_blocks * SCAN_TILE / 4;
+    BrickListArgs bl;
+    int rc = sphk_brick_list_prepare(c, &bl);
+    if (rc) return rc;
+    if (bl.nblocks > 0 && !c->brick_count_zero) {  // (a sort without its own hash pass: sph_counting_sort called twice)
+        SPH_HIP(c, hipMemsetAsync(c->brick_count, 0, 2 * sizeof(int), c->stream));
+    }
     hipLaunchKernelGGL(k_unstable_place, dim3(nb), dim3(TPB), 0, c->stream, d, c->rank_off, c->idx_unstable, c->dyn_count);
     SPH_LAUNCH_CHECK(c);
     if (sort_acc)
-        hipLaunchKernelGGL(k_stable_scatter<true>, dim3(nb), dim3(TPB), 0, c->stream, d, c->idx_unstable, c->xm[o],
-                           c->vf[o], c->aux[o], c->key[o], c->acc_tmp, c->dyn_list, c->dyn_count, zero_dst, zero_n4, c->brick_count);
+        hipLaunchKernelGGL(k_stable_scatter<true>, dim3(nb + bl.nblocks), dim3(TPB), bl.lds_bytes, c->stream, d, c->idx_unstable, c->xm[o],
+                           c->vf[o], c->aux[o], c->key[o], c->acc_tmp, c->dyn_list, c->dyn_count, zero_dst, zero_n4, bl);
     else
-        hipLaunchKernelGGL(k_stable_scatter<false>, dim3(nb), dim3(TPB), 0, c->stream, d, c->idx_unstable, c->xm[o],
-                           c->vf[o], c->aux[o], c->key[o], c->acc_tmp, c->dyn_list, c->dyn_count, zero_dst, zero_n4, c->brick_count);
+        hipLaunchKernelGGL(k_stable_scatter<false>, dim3(nb + bl.nblocks), dim3(TPB), bl.lds_bytes, c->stream, d, c->idx_unstable, c->xm[o],
+                           c->vf[o], c->aux[o], c->key[o], c->acc_tmp, c->dyn_list, c->dyn_count, zero_dst, zero_n4, bl);
     SPH_LAUNCH_CHECK(c);
     c->next_cells_zero = true;
-    c->brick_count_zero = true;
     c->cur = o;
     sph_invalidate_lists(c);
+    c->brick_count_zero = false;
+    c->bricks_valid = bl.nblocks > 0;  // (key recorded by sphk_brick_list_prepare)
     c->gcnt_written = false;
     c->aux_stale = false;  // (eos2 is in the old order: whoever needed density / pressure called sph_ensure_aux before)
     if (sort_acc) {

@@ -56,6 +56,7 @@ from __future__ import annotations
 import copy
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -992,9 +993,27 @@ def run_slab_bench(args, rank, world, local_rank):
     # the job runs on RCCL; torch.distributed P2P otherwise (gloo: several ranks sharing one GPU) or on request
     # (SPH_TRANSPORT=torch).
     want = os.environ.get("SPH_TRANSPORT", "native" if dist.get_backend() == "nccl" else "torch")
+    transport = None
     if want == "native":
-        transport = NativeTransport(s.ps, torch.device("cuda", local_rank))
-    else:
+        # self-test before the solver depends on it (multi-rank RCCL through the C ABI has only ever run as one rank on
+        # the development boxes): an all-reduce of ones must give the world size on every rank, else every rank falls
+        # back to the torch transport together
+        ok = 1
+        try:
+            transport = NativeTransport(s.ps, torch.device("cuda", local_rank))
+            probe = torch.ones(1, dtype=torch.int64, device=torch.device("cuda", local_rank))
+            ok = int(int(transport.all_reduce_sum(probe).item()) == world)
+        except Exception as e:          # noqa: BLE001 -- any failure here means "use the other transport"
+            print(f"[rank {rank}] native RCCL transport unavailable ({type(e).__name__}: {e}); falling back to torch.distributed P2P",
+                  file=sys.stderr, flush=True)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int64, device=torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if transport is not None:
+                transport.close()
+            transport = None
+    if transport is None:
         transport = TorchTransport(torch.device("cuda", local_rank))
     s.attach(transport)
     s.initialize()

@@ -1372,12 +1372,20 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
     hipStream_t st = sph_stream(c);
     int2* blist = c->use_side ? c->brick_list2 : c->brick_list;
     int* bcount = c->use_side ? c->brick_count2 : c->brick_count;
-    // A cached list also serves a sweep whose single target range lies INSIDE the cached one (slab mode: the force
-    // sweep over the owned layers after the density sweep over owned + first ghost layers): bricks listed for the wider
-    // range that hold no target of this sweep leave at T == 0.
-    const bool subset = c->bricks_valid && key[0] == c->bricks_key[0] && key[3] == key[4] && c->bricks_key[3] == c->bricks_key[4] &&
-                        key[1] >= c->bricks_key[1] && key[2] <= c->bricks_key[2];
-    if (c->use_side || !c->bricks_valid || (memcmp(key, c->bricks_key, sizeof(key)) != 0 && !subset)) {
+    // A cached list also serves a sweep whose target ranges lie INSIDE the cached (single) one -- slab mode: the force
+    // sweeps over the boundary layers (side stream) and the interior after the density sweep over owned + first ghost
+    // layers. Bricks listed for the wider range that hold no target of this sweep leave at T == 0. For a sweep that
+    // reads the neighbour lists this is not an economy but the rule: the entries are offsets into the tile of the brick
+    // that wrote them, and the adaptive cut depends on the target ranges, so a partition of its own would misread them.
+    const bool in1 = key[1] >= c->bricks_key[1] && key[2] <= c->bricks_key[2];
+    const bool in2 = key[3] == key[4] || (key[3] >= c->bricks_key[1] && key[4] <= c->bricks_key[2]);
+    const bool subset = c->bricks_valid && key[0] == c->bricks_key[0] && c->bricks_key[3] == c->bricks_key[4] && in1 && in2;
+    const bool cached = c->bricks_valid && (memcmp(key, c->bricks_key, sizeof(key)) == 0 || subset);
+    if (cached) {
+        blist = c->brick_list; bcount = c->brick_count;  // (read-only here; the side stream forked after it was built)
+    } else {
+        if (mode_reads_list<MODE>())
+            return sph_fail(c, SPH_E_INVALID, "the sweep reads neighbour lists but its targets lie outside the partition that wrote them");
         if (c->use_side || !c->brick_count_zero) SPH_HIP(c, hipMemsetAsync(bcount, 0, 2 * sizeof(int), st));
         if (!c->use_side) c->brick_count_zero = false;
         hipLaunchKernelGGL((k_brick_list<CFG>), dim3((ncg + TPB / 64 - 1) / (TPB / 64)), dim3(TPB), (size_t)(TPB / 64) * 5 * (d.nz + 1) * sizeof(int),

@@ -36,6 +36,17 @@ def fluid_only(counts=(10, 12, 8), start=(0.1, 0.1, 0.1), velocity=(0.0, -1.0, 0
     return {"Configuration": cfg, "FluidBlocks": [_block(0, start, lattice_end(start, counts), velocity)]}
 
 
+def crowded_fluid(counts=(24, 10, 20), start=(0.1, 0.1, 0.1), stiffness=1000.0):
+    """Two interleaved lattices (16 particles per cell, twice the rest density) under a soft equation of state: the
+    adaptive brick cut is then set by the 256-target limit, not by the brick height, so it depends on which x layers a
+    sweep targets."""
+    cfg = copy.deepcopy(BASE_CFG)
+    cfg["stiffness"] = stiffness
+    second = [s + 0.01 for s in start]
+    return {"Configuration": cfg, "FluidBlocks": [_block(0, start, lattice_end(start, counts), (0.5, -0.5, 0.0)),
+                                                  _block(0, second, lattice_end(second, counts), (0.5, -0.5, 0.0))]}
+
+
 def fluid_with_rigid_blocks(fluid_counts=(10, 10, 8), static_counts=(14, 2, 12), dyn_counts=(4, 4, 4)):
     """Fluid block resting on a static slab with a dynamic cube falling into it:
     exercises K4 (both), Akinci boundary pressure, two-way coupling and K9."""

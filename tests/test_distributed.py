@@ -89,12 +89,13 @@ def _single_domain(sd, steps):
 def _slab_scenes():
     a = scenes.fluid_only(counts=(20, 10, 8), start=(0.1, 0.1, 0.1), velocity=(1.5, -1.0, 0.0))   # drifts across the cuts
     b = scenes.fluid_with_rigid_blocks()
-    return [a, b]
+    c = scenes.crowded_fluid()      # bricks cut by the target limit: the boundary sweeps must keep the density sweep's cut
+    return [a, b, c]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("which", [0, 1])
+@pytest.mark.parametrize("which", [0, 1, 2])
 def test_local_slabs_match_single_domain(world, which):
     from sph_taichi_amd.distributed import SlabSolver, run_local_slabs, gather_by_pid
     sd = _slab_scenes()[which]

@@ -340,27 +340,41 @@ __device__ __forceinline__ void pair_physics(const DevView& d, Target& t, float 
 // with (1 - q) clamped at 0, so W, grad W and with them every contribution vanish from r = h on exactly as if the pair
 // had been rejected (particle_system.py:385), and the self pair (r = 0) multiplies finite coefficients by r = 0.  Only a
 // solid neighbour still needs the accept test (its reaction is scattered with atomics).
-__device__ __forceinline__ void pair_force_u_bf(const DevView& d, Target& t, float rx, float ry, float rz, float r2,
+// a uniform value held in a VGPR: on gfx950 a VALU instruction with an SGPR source issues at half rate
+// (profiles/r02b_ubench_valu_table2.txt: v_fma_f32 with one SGPR operand 4.4 cycles, all-VGPR 2.6)
+__device__ __forceinline__ float sph_in_vgpr(float x) { float r; asm("v_mov_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ __forceinline__ unsigned sph_in_vgpr(unsigned x) { unsigned r; asm("v_mov_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+// The constants of the pair term sit in VGPRs (sph_in_vgpr below).
+struct ForceK { float inv_h, kg, kw2, kw8, d2, w_d, visc, veps, cpk; };
+__device__ __forceinline__ ForceK force_k(const DevView& d) {
+    ForceK K;
+    K.inv_h = d.inv_h; K.kg = d.k_dw * d.inv_h;
+    K.kw2 = d.k_w * 2.0f; K.kw8 = d.k_w * 8.0f;
+    K.d2 = d.d2; K.w_d = d.w_d;
+    K.visc = d.visc_d_nu; K.veps = d.visc_eps;
+    K.cpk = -d.rho0 * d.m_V0;
+    return K;
+}
+__device__ __forceinline__ void pair_force_u_bf(const DevView& d, const ForceK& K, Target& t, float rx, float ry, float rz, float r2,
                                                 const float4 A, const float4 B, int gj, bool not_self) {
     const float rinv = __builtin_amdgcn_rsqf(r2 + 1e-30f);
     const float rn = r2 * rinv;
-    const float q = rn * d.inv_h;
     // sph_base.py:23-68 without branches: with t = (1-q)+ and u = (1/2-q)+,  W = k (2 t^3 - 8 u^3)  and
     // dW/dq = 6k (4 u^2 - t^2)  reproduce both pieces of the cubic spline and vanish from q = 1 on.
-    const float f = fminf(fmaxf(1.0f - q, 0.0f), 1.0f);
-    const float u = fminf(fmaxf(0.5f - q, 0.0f), 1.0f);
+    const float f = fminf(fmaxf(fmaf(-K.inv_h, rn, 1.0f), 0.0f), 1.0f);
+    const float u = fminf(fmaxf(fmaf(-K.inv_h, rn, 0.5f), 0.0f), 1.0f);
     const float f2 = f * f, u2 = u * u;
-    const float cg = d.k_dw * (4.0f * u2 - f2);
-    const float gc = rn > 1e-5f ? cg * (rinv * d.inv_h) : 0.0f;
+    const float cg = K.kg * (4.0f * u2 - f2);   // (k_dw / h) (4 u^2 - t^2)
+    const float gc = rn > 1e-5f ? cg * rinv : 0.0f;
     if (A.w > 0.0f) {
-        const float wq = d.k_w * 2.0f * (f2 * f) - d.k_w * 8.0f * (u2 * u);
-        const float w = (r2 > d.d2) ? wq : d.w_d;
+        const float wq = K.kw2 * (f2 * f) - K.kw8 * (u2 * u);
+        const float w = (r2 > K.d2) ? wq : K.w_d;
         const float c = t.st_c * w;                                               // WCSPH.py:93-102
         const float v_xy = (t.vx - B.x) * rx + (t.vy - B.y) * ry + (t.vz - B.z) * rz;
-        const float cv = d.visc_d_nu * A.w * v_xy * sph_rcp(r2 + d.visc_eps) * gc;  // WCSPH.py:105-116
+        const float cv = K.visc * A.w * v_xy * sph_rcp(r2 + K.veps) * gc;          // WCSPH.py:105-116
         const float k = cv - c;
         t.ax += k * rx; t.ay += k * ry; t.az += k * rz;
-        const float cp = -d.rho0 * d.m_V0 * (t.dpi + B.w) * gc;                    // WCSPH.py:51-57
+        const float cp = K.cpk * (t.dpi + B.w) * gc;                               // WCSPH.py:51-57
         t.px += cp * rx; t.py += cp * ry; t.pz += cp * rz;
     } else if (rn < d.h && not_self) {
         const float cp = -d.rho0 * (-A.w) * (t.dpi + t.dpj_solid) * gc;            // WCSPH.py:58-68
@@ -652,7 +666,9 @@ struct BrickCfg {
     static constexpr int off_cols(bool has_w) { return off_colg(has_w) + 64 * 4; }
     static constexpr int off_tg(bool has_w) { return off_cols(has_w) + 80 * 4; }
     static constexpr int off_toff(bool has_w) { return off_tg(has_w) + 64 * 4; }
-    static constexpr int off_tag(bool has_w) { return off_toff(has_w) + 80 * 4; }  // [NCELL][16] u16: tag|base of the cell's chunk k
+    // [NCELL][9] u32, filtering sweeps without a ring: the nine candidate runs of a target cell (column << 11 | first LDS slot | length << 16)
+    static constexpr int off_run(bool has_w) { return off_toff(has_w) + 80 * 4; }
+    static constexpr int off_tag(bool has_w) { return off_run(has_w) + (has_w && RD == 0 ? NCELL * 9 * 4 : 0); }  // [NCELL][16] u16: tag|base of the cell's chunk k
     static constexpr int off_ring(bool has_w) { return off_tag(has_w) + (RD > 0 ? NCELL * 16 * 2 : 0); }  // [RD][TPB] u32 hit masks
     static constexpr int bytes(bool has_w) { return off_ring(has_w) + RD * TPB * 4; }
     static_assert(NCOL <= 32, "column id must fit 5 bits of a list entry");
@@ -689,10 +705,6 @@ __global__ __launch_bounds__(TPB) void k_brick_list(DevView d, int nbx, int nby,
     sph_brick_list_block<CFG::BX, CFG::BY, CFG::BZ>(bv, nbx, nby, list, count, list_cap, tmax, smax, fixed_bz, (int)blockIdx.x, sm_bl);
 }
 
-// a uniform value held in a VGPR: on gfx950 a VALU instruction with an SGPR source issues at half rate
-// (profiles/r02b_ubench_valu_table2.txt: v_fma_f32 with one SGPR operand 4.4 cycles, all-VGPR 2.6)
-__device__ __forceinline__ float sph_in_vgpr(float x) { float r; asm("v_mov_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
-__device__ __forceinline__ unsigned sph_in_vgpr(unsigned x) { unsigned r; asm("v_mov_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
 // raw buffer descriptor (gfx9 dword 3): byte offsets in a VGPR, hardware range check against `bytes`
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t sph_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
@@ -742,6 +754,13 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
         const int kb = xcd * chunkl + (slot - chunkh);
         if (slot - chunkh >= chunkl || kb >= nbl) return;
         brick = brick_list[list_cap - 1 - kb];
+    }
+    if (d.ablate >> 20) {  // EXPERIMENT: stagger the first resident workgroups (do equal bricks run in convoy?)
+        const int u = (d.ablate >> 20) & 15, nfirst = 256 * ((d.ablate >> 24) & 15);
+        if ((int)blockIdx.x < nfirst) {
+            const unsigned k = ((blockIdx.x * 2654435761u) >> 20) % 5u;
+            for (unsigned a = 0; a < k * (unsigned)u; ++a) __builtin_amdgcn_s_sleep(16);
+        }
     }
     {
     // (column group, first z layer | height << 16): the partition of k_brick_list
@@ -851,6 +870,27 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                 if (sColS[col + step] <= idx) col += step;
             buf[u] = ((MODE == GM_FORCE_FUSED_U || mode_is_df_iter_u<MODE>()) ? d.stg : d.xm)[sColG[col] + idx];
         }
+        // SPH_VAR_GROUPS: the nine candidate runs of every target cell, once per brick instead of once per target (all
+        // targets of a cell walk the same runs), computed while the staging loads are in flight: entry (cell, r) =
+        // column << 11 | first LDS slot | length << 16, length 0 for a column outside the domain.
+        if (V_GROUPS) {
+            unsigned* const sRun = reinterpret_cast<unsigned*>(smem + CFG::off_run(HAS_W));
+            for (int e = tid; e < CFG::NCELL * 9; e += TPB) {
+                const int cell = e / 9, r = e - cell * 9;
+                const int colb = cell / CFG::BZ, zc = cell - colb * CFG::BZ;
+                const int ix = cx0 + colb / CFG::BY, iy = cy0 + colb % CFG::BY, cz = cz0 + zc;
+                const int nx = ix + r / 3 - 1, ny = iy + r % 3 - 1;
+                unsigned word = 0u;
+                if (ix < cx1 && iy < cy1 && cz < cz1 && nx >= 0 && nx < d.nx && ny >= 0 && ny < d.ny) {
+                    const int klo = (cz > 0 ? cz - 1 : 0) - sz0, khi = (cz < d.nz - 1 ? cz + 1 : d.nz - 1) - sz0;
+                    const int ncol = (nx - sx0) * ncy + (ny - sy0);
+                    const int rel = -sColG[ncol];
+                    const int lo = sCE[ncol * CFG::NZS + klo] + rel, hi = sCE[ncol * CFG::NZS + khi + 1] + rel;
+                    word = ((unsigned)ncol << 11) | (unsigned)lo | ((unsigned)(hi - lo) << 16);
+                }
+                sRun[e] = word;
+            }
+        }
 #pragma unroll
         for (int u = 0; u < CFG::PER; ++u) {
             const int idx = tid + u * TPB;
@@ -949,7 +989,7 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                 const float mVj = *reinterpret_cast<const float*>(smem + CFG::off_w(true) + (aq >> 2));
                 const float rx = fmaf(0.5f, q4.x, txl_), ry = fmaf(0.5f, q4.y, tyl_), rz = fmaf(0.5f, q4.z, tzl_);
                 const float r2 = rx * rx + ry * ry + rz * rz;
-                const float qn = r2 * __builtin_amdgcn_rsqf(r2 + 1e-30f) * v_inv_h;  // r2 = 0 (self): 0 * 1e15 = 0
+                const float qn = __builtin_amdgcn_sqrtf(r2) * v_inv_h;  // v_sqrt_f32 (1 ulp; exact 0 for the self pair)
                 // sph_base.py:23-44 in one expression for both branches: with t = (1-q)+ and
                 // u = (1/2-q)+ the cubic spline is k (2 t^3 - 8 u^3) -- for q <= 1/2 this IS
                 // k (6 q^3 - 6 q^2 + 1), beyond it u = 0 leaves the outer branch, from q = 1 on t = 0.
@@ -1046,27 +1086,24 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                 // most hits), the four edge runs, the four corner runs: phase p then costs the wave about the p-th
                 // largest count of its busiest lane (tools/emission_model.py: 109 -> ~69 trips per wave in a settled flow).
                 unsigned mk[9], tk[9];
+                const unsigned* const runs = reinterpret_cast<const unsigned*>(smem + CFG::off_run(HAS_W)) +
+                                             (((ix - cx0) * CFG::BY + (iy - cy0)) * CFG::BZ + (cz - cz0)) * 9;
+                bool longrun = false;
 #pragma unroll
                 for (int r = 0; r < 9; ++r) {
-                    const int nx = ix + r / 3 - 1, ny = iy + r % 3 - 1;
-                    const bool ok = nx >= 0 && nx < d.nx && ny >= 0 && ny < d.ny;
-                    const int ncol = ok ? (nx - sx0) * ncy + (ny - sy0) : 0;
-                    const int rel = -sColG[ncol];
-                    const int lo = sCE[ncol * CFG::NZS + klo] + rel;
-                    const int hi = ok ? sCE[ncol * CFG::NZS + khi + 1] + rel : lo;
-                    const int n = min(32, hi - lo);
-                    mk[r] = n > 0 ? filter_chunk(lo, n) : 0u;
-                    tk[r] = ((unsigned)ncol << 11) | (unsigned)lo;
+                    const unsigned w = runs[r];
+                    const int len = (int)(w >> 16);
+                    mk[r] = len > 0 ? filter_chunk((int)(w & 2047u), min(32, len)) : 0u;
+                    tk[r] = w & 0xffffu;
+                    longrun |= len > 32;
                 }
-                for (int r = 0; r < 9; ++r) {  // (rare) chunks beyond the first 32 candidates of a run
-                    const int nx = ix + r / 3 - 1, ny = iy + r % 3 - 1;
-                    if (nx < 0 || nx >= d.nx || ny < 0 || ny >= d.ny) continue;
-                    const int ncol = (nx - sx0) * ncy + (ny - sy0);
-                    const int rel = -sColG[ncol];
-                    const int lo = sCE[ncol * CFG::NZS + klo] + rel, hi = sCE[ncol * CFG::NZS + khi + 1] + rel;
-                    for (int base = lo + 32; base < hi; base += 32)
-                        emit_micro(filter_chunk(base, min(32, hi - base)), ((unsigned)ncol << 11) | (unsigned)base, (unsigned)base << 4);
-                }
+                if (longrun)  // (rare) chunks beyond the first 32 candidates of a run
+                    for (int r = 0; r < 9; ++r) {
+                        const unsigned w = runs[r];
+                        const int lo = (int)(w & 2047u), hi = lo + (int)(w >> 16);
+                        for (int base = lo + 32; base < hi; base += 32)
+                            emit_micro(filter_chunk(base, min(32, hi - base)), (w & 0xf800u) | (unsigned)base, (unsigned)base << 4);
+                    }
 #pragma unroll
                 for (int r = 0; r < 9; ++r) tk[r] |= (unsigned)__popc(mk[r]) << 16;
                 // ten compare-exchanges on the words (hits << 16 | tag|base), the mask travelling with its word
@@ -1118,6 +1155,8 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
             const float txl = t.x - Ox, tyl = t.y - Oy, tzl = t.z - Oz;
             (void)txl; (void)tyl; (void)tzl;
             struct Slot { float4 A, B, C; int g, j; };
+            ForceK FK;
+            if (V_BF) FK = force_k(d);
             // V_BF: list rows and the gat gather through raw buffers (32-bit byte offsets instead of 64-bit pointer arithmetic)
             const __amdgpu_buffer_rsrc_t grs = sph_rsrc(d.gat, (unsigned)d.N * 16u);
             const __amdgpu_buffer_rsrc_t lrs3 = sph_rsrc(glist, (unsigned)SPH_GLIST_ROWS * (unsigned)cap * 2u);
@@ -1147,7 +1186,7 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                 const float ry = HAS_W ? fmaf(0.5f, s_.A.y, tyl) : t.y - s_.A.y;
                 const float rz = HAS_W ? fmaf(0.5f, s_.A.z, tzl) : t.z - s_.A.z;
                 const float r2 = rx * rx + ry * ry + rz * rz;
-                if (V_BF) { pair_force_u_bf(d, t, rx, ry, rz, r2, s_.A, s_.B, s_.g, s_.j != li); return; }
+                if (V_BF) { pair_force_u_bf(d, FK, t, rx, ry, rz, r2, s_.A, s_.B, s_.g, s_.j != li); return; }
                 const float rinv = sph_rsq(r2);
                 const float rn = r2 * rinv;
                 if (sph_within<MODE>(d, r2, rn) && s_.j != li)  // particle_system.py:385

@@ -153,7 +153,13 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     rc = rc ? rc : alloc_dev(c, (void**)&c->rank_off, cap * 4);
     rc = rc ? rc : alloc_dev(c, (void**)&c->idx_unstable, cap * 4);
     rc = rc ? rc : alloc_dev(c, (void**)&c->scan_sums, (size_t)(c->scan_blocks + 1) * 4);
-    rc = rc ? rc : alloc_dev(c, (void**)&c->glist, cap * 2 * SPH_GLIST_ROWS);
+    {   // four consecutive entries of a particle form one 8-byte word; a group of entries spans a power of two of bytes
+        int sh = 3;
+        while (((size_t)1 << sh) < cap * 8) ++sh;
+        const bool reach = (((unsigned long long)(SPH_GLIST_ROWS / 4 + 4)) << sh) <= (1ull << 32);   // (+ the readers' look-ahead)
+        c->glist_shift = reach ? sh : 0;
+        rc = rc ? rc : alloc_dev(c, (void**)&c->glist, reach ? ((size_t)(SPH_GLIST_ROWS / 4) << sh) : 16);
+    }
     rc = rc ? rc : alloc_dev(c, (void**)&c->gcnt, cap);
     // bricks have a 4x2-column footprint and a height the list builder chooses (k_brick_list): at worst one per z layer
     c->brick_cap = ((params->grid_num[0] + 3) / 4) * ((params->grid_num[1] + 1) / 2) * params->grid_num[2] + 8;

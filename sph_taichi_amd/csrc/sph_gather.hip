@@ -633,7 +633,6 @@ __global__ __launch_bounds__(TPB) void k_gather_bvol_split(DevView d, const int*
 // offset once per hit with a SATURATING add (a target can have as many hits as the tile has records; rows >= LISTCAP
 // are dropped by the buffer's range check, and an offset stuck at 2^32 - 1 stays out of range); the list readers form
 // the offsets of up to 8 rows past a list's end before clamping them.
-#define SPH_VOFF_ROWS (SPH_GLIST_ROWS + 8)
 #define SPH_BRICK_MAX_NZ 1000  // k_brick_list keeps five per-layer arrays per column group in LDS; taller grids take the cell walk
 #define SPH_CNT_WALK 255  // gcnt sentinel: this target must take the exact global cell walk (its brick's shell overflowed the LDS tile)
 #define SPH_CNT_LIST_OVF 254  // same consequence, other cause: the target's own list outgrew LISTCAP
@@ -716,7 +715,7 @@ template <int MODE, class CFG, int VAR = 0>
 __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gather_brick(DevView d, int nby, const int2* __restrict__ brick_list,
                                                       const int* __restrict__ brick_count,
                                                       unsigned short* __restrict__ glist,
-                                                      unsigned char* __restrict__ gcnt, int cap, int list_cap) {
+                                                      unsigned char* __restrict__ gcnt, int cap, int list_cap, int lshift) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool HAS_W = !mode_reads_list<MODE>();
     constexpr bool V_RING = (VAR & SPH_VAR_RING) != 0 && CFG::RD > 0 && mode_inline_physics<MODE>();
@@ -948,13 +947,19 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
             // The list rows go through a raw buffer whose size is LISTCAP rows -- a store into row >= LISTCAP is dropped
             // by the hardware range check (no compare, no branch), the byte offset is one 32-bit VGPR -- and the
             // constants of the pair term sit in VGPRs (an SGPR source halves a VALU instruction's issue rate).
-            const __amdgpu_buffer_rsrc_t lrs = sph_rsrc(glist, (unsigned)CFG::LISTCAP * (unsigned)cap * 2u);
-            unsigned voff = (unsigned)gi * 2u;
-            const unsigned vcap2 = sph_in_vgpr((unsigned)cap * 2u);
+            // Entry r of particle i lives at (r >> 2) << lshift | i * 8 | (r & 3) * 2: four consecutive entries of a
+            // particle are one 8-byte word (the list-reading sweeps fetch them with one load), a wave's words of one
+            // entry group are contiguous, and a group spans 2^lshift >= cap * 8 bytes.  The running offset `voff` keeps the
+            // particle field filled with ones (lmask), so that `+ 2` carries out of the entry field straight into the group
+            // field: next = (voff + 2, saturating) | lmask, address = voff ^ lflip.
+            const __amdgpu_buffer_rsrc_t lrs = sph_rsrc(glist, (unsigned)(SPH_GLIST_ROWS / 4) << lshift);
+            const unsigned lmask = sph_in_vgpr((1u << lshift) - 8u);
+            const unsigned lflip = lmask ^ ((unsigned)gi * 8u);
+            unsigned voff = lmask;
             const float v_inv_h = sph_in_vgpr(d.inv_h);
             const float v_kw2 = sph_in_vgpr(d.k_w * 2.0f);
             const float v_kw8 = sph_in_vgpr(d.k_w * 8.0f);
-            (void)lrs; (void)voff; (void)vcap2; (void)v_inv_h; (void)v_kw2; (void)v_kw8;
+            (void)lrs; (void)voff; (void)lflip; (void)v_inv_h; (void)v_kw2; (void)v_kw8;
 // Hits are collected in a per-run bitmask register (no LDS traffic while filtering) and turned into list
 // entries once per chunk of <= 32 candidates: ~7 ds_write per run instead of one per candidate.
 // One candidate = 3 FMA + 1 add + 1 v_alignbit: the test value r2' - thr' is negative for a hit, and alignbit shifts
@@ -1006,8 +1011,8 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                 while (mask) {
                     const unsigned bit = (unsigned)__ffs((int)mask) - 1u;
                     mask &= mask - 1u;
-                    if (!(d.ablate & 2)) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(tagbase + bit), lrs, (int)voff, 0, 0);
-                    voff = __builtin_elementwise_add_sat(voff, vcap2);
+                    if (!(d.ablate & 2)) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(tagbase + bit), lrs, (int)(voff ^ lflip), 0, 0);
+                    voff = __builtin_elementwise_add_sat(voff, 2u) | lmask;
                     if (INLINE_PHYS && !(d.ablate & 32)) pair_term(base16 + (bit << 4));
                 }
             };
@@ -1067,8 +1072,8 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                         asm volatile("ds_read_b32 %0, %2\n\tds_read_u16 %1, %3"
                                      : "=&v"(m_), "=&v"(tg_) : "v"(ring_a + (unsigned)tk * (unsigned)(TPB * 4)), "v"(tag_a + (chunk_id(tk) << 1)));
                     }
-                    if (!(d.ablate & 2)) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(cb + bit), lrs, (int)voff, 0, 0);
-                    voff = __builtin_elementwise_add_sat(voff, vcap2);
+                    if (!(d.ablate & 2)) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(cb + bit), lrs, (int)(voff ^ lflip), 0, 0);
+                    voff = __builtin_elementwise_add_sat(voff, 2u) | lmask;
                     if (!(d.ablate & 32)) pair_term((((cb & 2047u) + bit) << 4));
                     cur = rest;
                     if (rest == 0u) {
@@ -1132,6 +1137,15 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                         emit_micro(filter_chunk(base, min(32, hi - base)), ((unsigned)ncol << 11) | (unsigned)base, (unsigned)base << 4);
                 }
             }
+            // The readers fetch whole groups of four: the rest of the last group is filled with the target's own entry
+            // (always a staged record; entries beyond the count are fetched, never paired).
+            if ((cnt & 3) && !(d.ablate & 2)) {
+                const unsigned self_e = ((unsigned)col << 11) | ((unsigned)(gi - sColG[col]) & 2047u);
+                for (int u = cnt & 3; u < 4; ++u) {
+                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)self_e, lrs, (int)(voff ^ lflip), 0, 0);
+                    voff = __builtin_elementwise_add_sat(voff, 2u) | lmask;
+                }
+            }
             // list overflow (extreme compression): the list-reading sweep must take the exact slow path; this
             // sweep too, unless its pair term was already summed inline (complete regardless of the list length)
             const bool list_ovf = cnt > CFG::LISTCAP && !(d.ablate & 8);
@@ -1159,7 +1173,7 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
             if (V_BF) FK = force_k(d);
             // V_BF: list rows and the gat gather through raw buffers (32-bit byte offsets instead of 64-bit pointer arithmetic)
             const __amdgpu_buffer_rsrc_t grs = sph_rsrc(d.gat, (unsigned)d.N * 16u);
-            const __amdgpu_buffer_rsrc_t lrs3 = sph_rsrc(glist, (unsigned)SPH_GLIST_ROWS * (unsigned)cap * 2u);
+            const __amdgpu_buffer_rsrc_t lrs3 = sph_rsrc(glist, (unsigned)(SPH_GLIST_ROWS / 4) << lshift);
             (void)grs; (void)lrs3;
             auto fetch = [&](Slot& s_, unsigned e) {
                 s_.j = e & 2047;
@@ -1193,52 +1207,49 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                     pair_physics<MODE>(d, t, rx, ry, rz, r2, rn, rinv, s_.A, s_.B, s_.C, s_.g);
             };
             if (cnt > 0) {
-                const unsigned short* gl = glist + gi;  // entry k of this target: gl[k * cap]
-                const int last = cnt - 1;
-                const unsigned vlast = ((unsigned)last * (unsigned)cap + (unsigned)gi) * 2u;
-                // entry `row` of this lane, clamped to its last one (row is wave-uniform: row * cap is scalar arithmetic)
-#ifdef SPH_PROFILE_FORCE
-                unsigned lde_prev = 0;  // (profiling build, ablate bit 6: only every fourth entry is loaded, the others repeat it)
-#endif
-                auto lde = [&](int row) -> unsigned {
-#ifdef SPH_PROFILE_FORCE
-                    if ((d.ablate & 64) && (row & 3)) return lde_prev;
-                    if (d.ablate & 64) return lde_prev = gl[(size_t)min(row, last) * cap];
-#endif
-                    if (V_BF || V_DEEP) return (unsigned)__builtin_amdgcn_raw_buffer_load_b16(lrs3, (int)min(((unsigned)row * (unsigned)cap + (unsigned)gi) * 2u, vlast), 0, 0);
-                    return gl[(size_t)min(row, last) * cap];
+                // Four entries per load: group g of this lane (g is wave-uniform, clamped to the lane's last group, so every
+                // entry that is fetched is one the density sweep wrote -- its own or the padding behind them).
+                const unsigned gi8 = (unsigned)gi * 8u;
+                const int lastg = (cnt - 1) >> 2;
+                auto ldg = [&](int g) -> uint2 {
+                    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                    const v2u w = __builtin_bit_cast(v2u, __builtin_amdgcn_raw_buffer_load_b64(lrs3, (int)(((unsigned)min(g, lastg) << lshift) + gi8), 0, 0));
+                    return make_uint2(w.x, w.y);
                 };
-                Slot s0, s1, s2;  // three sets: the records of entries k+1 and k+2 are in flight while pair k is computed
-                unsigned ea = lde(0), eb = lde(1), ec = lde(2);
-                fetch(s0, ea);
-                fetch(s1, eb);
+                // Four slots, three of them live at any time: the records of pairs k+1 and k+2 are in flight while pair k
+                // is computed (the fourth name only keeps the rotation in step with the groups of four).
+                Slot s0, s1, s2, s3;
+                uint2 cur = ldg(0), nxt = ldg(1);
+                fetch(s0, cur.x & 0xffffu);
+                fetch(s1, cur.x >> 16);
                 if (V_DEEP) {
-                    // The entry of pair k+3 heads a dependent chain (entry -> column table in LDS -> record gather)
-                    // and, loaded where it is decoded, has one pair's time (~300 cycles) to come back from L2.  Here
-                    // the entries of the NEXT round are loaded at the top of this one: a whole round of slack.
-                    unsigned q0 = lde(3), q1 = lde(4), q2 = lde(5);
-                    for (int k = 0; k < cnt; k += 3) {
-                        const unsigned n0 = lde(k + 6), n1 = lde(k + 7), n2 = lde(k + 8);
-                        fetch(s2, ec);
+                    // The entries head a dependent chain (entry -> column table in LDS -> record gather): the group three
+                    // ahead is requested at the top of the round, two rounds of slack for its trip to L2.
+                    uint2 nn = ldg(2);
+                    for (int k = 0; k < cnt; k += 4) {
+                        const uint2 n3 = ldg((k >> 2) + 3);
+                        fetch(s2, cur.y & 0xffffu);
                         pair(s0);
-                        fetch(s0, q0);
+                        fetch(s3, cur.y >> 16);
                         if (k + 1 < cnt) pair(s1);
-                        fetch(s1, q1);
-                        ec = q2;
+                        fetch(s0, nxt.x & 0xffffu);
                         if (k + 2 < cnt) pair(s2);
-                        q0 = n0; q1 = n1; q2 = n2;
+                        fetch(s1, nxt.x >> 16);
+                        if (k + 3 < cnt) pair(s3);
+                        cur = nxt; nxt = nn; nn = n3;
                     }
                 } else
-                for (int k = 0; k < cnt; k += 3) {
-                    fetch(s2, ec);
-                    ea = lde(k + 3);
+                for (int k = 0; k < cnt; k += 4) {
+                    const uint2 nn = ldg((k >> 2) + 2);
+                    fetch(s2, cur.y & 0xffffu);
                     pair(s0);
-                    fetch(s0, ea);
-                    eb = lde(k + 4);
+                    fetch(s3, cur.y >> 16);
                     if (k + 1 < cnt) pair(s1);
-                    fetch(s1, eb);
-                    ec = lde(k + 5);
+                    fetch(s0, nxt.x & 0xffffu);
                     if (k + 2 < cnt) pair(s2);
+                    fetch(s1, nxt.x >> 16);
+                    if (k + 3 < cnt) pair(s3);
+                    cur = nxt; nxt = nn;
                 }
             }
         }
@@ -1341,11 +1352,11 @@ static int launch_simple(SphContext* c, const int* list, int n) {
     return 0;
 }
 
-// The brick sweeps address their list rows with 32-bit byte offsets (SPH_VOFF_ROWS) and k_brick_list keeps per-layer
-// arrays in LDS (SPH_BRICK_MAX_NZ): contexts beyond either limit (> 20.6 M particles of capacity, > 1000 cell layers in
-// z) take the per-particle cell walk.
+// The brick sweeps address their list entries with 32-bit byte offsets (SPH_GLIST_ROWS / 4 groups of 2^glist_shift bytes,
+// sph_api.hip) and k_brick_list keeps per-layer arrays in LDS (SPH_BRICK_MAX_NZ): contexts beyond either limit (> 16.7 M
+// particles of capacity, > 1000 cell layers in z) take the per-particle cell walk.
 static bool brick_ok(const SphContext* c) {
-    return (unsigned long long)c->cap * 2ull * SPH_VOFF_ROWS < (1ull << 32) && c->p.grid_num[2] <= SPH_BRICK_MAX_NZ;
+    return c->glist_shift > 0 && c->p.grid_num[2] <= SPH_BRICK_MAX_NZ;
 }
 
 // identity of a partition: footprint, cut rule, limits (the target ranges complete the key)
@@ -1436,7 +1447,7 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
         }
     }
     hipLaunchKernelGGL((k_gather_brick<MODE, CFG, VAR>), dim3(grid), dim3(TPB), bytes, st, d, nby, blist, bcount, c->glist,
-                       c->gcnt, c->cap, c->brick_cap);
+                       c->gcnt, c->cap, c->brick_cap, c->glist_shift);
     SPH_LAUNCH_CHECK(c);
     return 0;
 }

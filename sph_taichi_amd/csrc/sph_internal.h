@@ -7,7 +7,7 @@
 //   aux[cap] float4 = (m, density, pressure, bits(pid)) hot, ping-pong
 //   eos[cap] float4 = (p/rho^2, m/rho_raw, m, rho)    written by density+EOS, read by force
 //                     (DFSPH: (dfsph_factor, density_adv, m, rho))
-//   glist[96*cap] u16, gcnt[cap] u8                   neighbour lists (SPH_GLIST_ROWS rows): row k of particle i at glist[k*cap + i]
+//   glist[24 << glist_shift bytes] u16, gcnt[cap] u8  neighbour lists: entry r of particle i at (r >> 2) << glist_shift | i * 8 | (r & 3) * 2
 //   acc[cap] float4 = (ax, ay, az, 0)
 //   key[cap] int    = grid_ids                        ping-pong
 //   x0_cold [3*cap] f32, color_cold [3*cap] i32       indexed by pid, never moved
@@ -110,7 +110,9 @@ struct SphContext {
     int* rank_off;     // [cap] arbitrary intra-cell offset from the histogram atomics
     int* idx_unstable; // [cap]
     int* scan_sums;    // block sums for the scan
-    unsigned short* glist;  // [SPH_GLIST_ROWS * cap] neighbour lists handed from the density to the force sweep
+    unsigned short* glist;  // neighbour lists handed from the density to the force sweep: SPH_GLIST_ROWS / 4 entry groups of
+                            // 2^glist_shift bytes, entry r of particle i at (r >> 2) << glist_shift | i * 8 | (r & 3) * 2
+    int glist_shift;        // smallest shift with cap * 8 <= 2^shift; 0 = no lists (32-bit offsets would not reach: cell walk)
     unsigned char* gcnt;    // [cap] list lengths (255 = take the global cell walk)
     int2* brick_list;       // [brick_cap] bricks of the sweep being launched: (column group, first z layer | height << 16)
     int* brick_count;       // device counter

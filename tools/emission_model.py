@@ -121,6 +121,11 @@ def analyse(x, h, label, BX=4, BY=2, BZ=4, margin=1.0002, sort_cells=False):
                     res["merged"] += int(H.sum(1).max())
                     # antipodal pairs emitted jointly: (dx,dy) with (-dx,-dy), centre alone
                     res["paired"] = res.get("paired", 0) + int(sum((H[:, a] + H[:, 8 - a]).max() for a in range(4)) + H[:, 4].max())
+                    S = -np.sort(-H, axis=1)
+                    # balanced pairs after a full sort: largest alone, then (2nd + 9th), (3rd + 8th), (4th + 7th), (5th + 6th)
+                    res["bal_pairs"] = res.get("bal_pairs", 0) + int(S[:, 0].max() + sum((S[:, 1 + a] + S[:, 8 - a]).max() for a in range(4)))
+                    # three joint loops: (1st + 6th + 7th), (2nd + 5th + 8th), (3rd + 4th + 9th)
+                    res["bal_triples"] = res.get("bal_triples", 0) + int((S[:, 0] + S[:, 5] + S[:, 6]).max() + (S[:, 1] + S[:, 4] + S[:, 7]).max() + (S[:, 2] + S[:, 3] + S[:, 8]).max())
                     res["ideal"] += float(H.sum(1).mean())
                     res["filt_nat"] += int((((rlen[ids] + 7) // 8) * 8).max(0).sum())
                     res["filt_sorted"] = res.get("filt_sorted", 0) + int((((-np.sort(-rlen[ids], axis=1) + 7) // 8) * 8).max(0).sum())
@@ -131,6 +136,7 @@ def analyse(x, h, label, BX=4, BY=2, BZ=4, margin=1.0002, sort_cells=False):
     print(f"   mean hits per lane {res['ideal'] / w:.1f};  emission trips per wave: per 32-candidate chunk (the kernel) {res.get('chunked', 0) / w:.1f}, per run {res['natural'] / w:.1f}, "
           f"mirrored {res['mirrored'] / w:.1f}, centre + sorted edges + sorted corners {res.get('group_sorted', 0) / w:.1f}, antipodal pairs {res.get('paired', 0) / w:.1f}, sorted {res['sorted'] / w:.1f}, merged {res['merged'] / w:.1f};  "
           f"filter candidates per wave (lock-step, 8 per trip) {res['filt_nat'] / w:.0f}, runs walked longest first {res.get('filt_sorted', 0) / w:.0f}, a lane's own {res.get('filt_own', 0) / w:.0f}")
+    print(f"   joint loops: largest + four balanced pairs {res.get('bal_pairs', 0) / w:.1f}, three balanced triples {res.get('bal_triples', 0) / w:.1f}")
     print(f"   as built (first chunk in registers, further chunks at once): mirrored {res.get('k_mirror', 0) / w:.1f}, sorted {res.get('k_sorted', 0) / w:.1f}, centre + sorted edges + sorted corners {res.get('k_group', 0) / w:.1f}")
     return res
 

@@ -245,8 +245,8 @@ def main():
         solver.step(args.warmup)
         solver.dt[None] = 0.0
         for mask, what in [(0, "full"), (1, "no phase 2"), (2, "no list write-out (force sweep reads stale lists)"),
-                           (64, "force: one list-entry load per 4 pairs"), (128, "force: no neighbour gather"),
-                           (192, "force: neither"), (16, "filter only, no hit emitted"), (32, "no pair term in the emission loop"), (34, "emission: bit loop only"),
+                           (128, "force: no neighbour gather (only in a -DSPH_PROFILE_FORCE build)"),
+                           (16, "filter only, no hit emitted"), (32, "no pair term in the emission loop"), (34, "emission: bit loop only"),
                            (4, "no phase 1"), (7, "staging + target setup only")]:
             ps.set_option(_lib.OPT_DEBUG_ABLATE, mask)
             dt, tm = run(args.gather_impl, args.brick_shape, 1, 20, 2)

@@ -627,12 +627,12 @@ __global__ __launch_bounds__(TPB) void k_gather_bvol_split(DevView d, const int*
 // List entries are u16: (shell column << 11) | LDS slot, so CAP <= 2048 and
 // NCOL <= 32; the global index of a slot is slot + sColG[col] (sColG = global start - LDS start of the column).
 // In the fused step the density sweep writes each target's list to HBM
-// (glist[k*cap + i], gcnt[i]) and the force sweep -- same positions, same
-// brick layout -- reads it back instead of filtering again.
-// The buffer-addressed variants keep byte offsets (row * cap + i) * 2 in 32 bits.  The emission loop advances its
-// offset once per hit with a SATURATING add (a target can have as many hits as the tile has records; rows >= LISTCAP
-// are dropped by the buffer's range check, and an offset stuck at 2^32 - 1 stays out of range); the list readers form
-// the offsets of up to 8 rows past a list's end before clamping them.
+// (glist, gcnt[i]) and the force sweep -- same positions, same brick layout -- reads it back instead of filtering again.
+// Entry r of particle i sits at byte (r >> 2) << lshift | i * 8 | (r & 3) * 2 (2^lshift >= cap * 8, sph_api.hip): four
+// consecutive entries are one 8-byte word, which the readers fetch with one load per four pairs.  All offsets are 32-bit.
+// The emission loop advances its offset once per hit with a SATURATING add (a target can have as many hits as the tile
+// has records; groups beyond the allocation are dropped by the buffer's range check, and an offset stuck at 2^32 - 1
+// stays out of range); the readers clamp the group index to the lane's last group, so every entry they fetch was written.
 #define SPH_BRICK_MAX_NZ 1000  // k_brick_list keeps five per-layer arrays per column group in LDS; taller grids take the cell walk
 #define SPH_CNT_WALK 255  // gcnt sentinel: this target must take the exact global cell walk (its brick's shell overflowed the LDS tile)
 #define SPH_CNT_LIST_OVF 254  // same consequence, other cause: the target's own list outgrew LISTCAP
@@ -944,9 +944,9 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
             const float txl_ = t.x - Ox, tyl_ = t.y - Oy, tzl_ = t.z - Oz;
             // superset filter (exact r < h test in phase 2): r2 - |x_i'|^2 < h^2 (1 + 2e-4) - |x_i'|^2
             const float thr = d.h * d.h * 1.0002f - (txl_ * txl_ + tyl_ * tyl_ + tzl_ * tzl_);
-            // The list rows go through a raw buffer whose size is LISTCAP rows -- a store into row >= LISTCAP is dropped
-            // by the hardware range check (no compare, no branch), the byte offset is one 32-bit VGPR -- and the
-            // constants of the pair term sit in VGPRs (an SGPR source halves a VALU instruction's issue rate).
+            // The list goes through a raw buffer the size of its 24 entry groups -- a store beyond them is dropped by the
+            // hardware range check (no compare, no branch), the byte offset is one 32-bit VGPR -- and the constants of
+            // the pair term sit in VGPRs (an SGPR source halves a VALU instruction's issue rate).
             // Entry r of particle i lives at (r >> 2) << lshift | i * 8 | (r & 3) * 2: four consecutive entries of a
             // particle are one 8-byte word (the list-reading sweeps fetch them with one load), a wave's words of one
             // entry group are contiguous, and a group spans 2^lshift >= cap * 8 bytes.  The running offset `voff` keeps the
@@ -1171,7 +1171,7 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
             struct Slot { float4 A, B, C; int g, j; };
             ForceK FK;
             if (V_BF) FK = force_k(d);
-            // V_BF: list rows and the gat gather through raw buffers (32-bit byte offsets instead of 64-bit pointer arithmetic)
+            // the list groups through a raw buffer; V_BF: the gat gather too (32-bit byte offsets instead of 64-bit pointer arithmetic)
             const __amdgpu_buffer_rsrc_t grs = sph_rsrc(d.gat, (unsigned)d.N * 16u);
             const __amdgpu_buffer_rsrc_t lrs3 = sph_rsrc(glist, (unsigned)(SPH_GLIST_ROWS / 4) << lshift);
             (void)grs; (void)lrs3;

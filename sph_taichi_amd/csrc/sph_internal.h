@@ -25,7 +25,7 @@
 #define SPH_MATERIAL_SOLID 0  // particle_system.py:30
 #define SPH_MATERIAL_FLUID 1  // particle_system.py:31
 #define SPH_MAX_TIMED_STEPS 128
-#define SPH_GLIST_ROWS 96  // list rows per particle; lists up to LISTCAP = 95 entries (developed dam-break flows reach 57, profiles/r02i)
+#define SPH_GLIST_ROWS 96  // list entries allocated per particle (24 groups of four); lists up to LISTCAP = 95 entries (developed dam-break flows reach 58, profiles/r03i)
 #define SPH_DF_ERR_BLOCKS 512
 #define SPH_VAR_DEFAULT (SPH_VAR_GROUPS | SPH_VAR_FORCE_BF | SPH_VAR_DEEP)  // SPH_OPT_KERNEL_VARIANT when the caller does not choose: the fastest rows of profiles/r03f_variants_partition_x_emission.json (density) and r02g_variants_force.json (force)
 

@@ -1477,7 +1477,10 @@ static int launch_brick(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, in
 // force sweep over the targets of x layers [lo, hi) only (slab mode: boundary layers first, interior later)
 int sphk_gather_layers(SphContext* c, int mode, int lo, int hi, int lo2, int hi2) {
     if (c->N <= 0 || (hi <= lo && hi2 <= lo2)) return 0;
-    if (mode != GM_FORCE_FUSED || c->opt_gather_impl == 0 || !brick_ok(c)) return sph_fail(c, SPH_E_INVALID, "layer-restricted sweeps need the brick force kernel");
+    if (c->opt_gather_impl == 1 && !brick_ok(c))
+        return sph_fail(c, SPH_E_INVALID, "a slab rank needs the brick sweeps, and this context is beyond their reach (capacity > 16.7 M particles "
+                                          "or more than 1000 cell layers in z): cut the domain into more slabs");
+    if (mode != GM_FORCE_FUSED || c->opt_gather_impl == 0) return sph_fail(c, SPH_E_INVALID, "layer-restricted sweeps need the brick force kernel");
     if (hi < lo) hi = lo;
     if (c->uniform_state == 1 && c->lists_valid && c->stg_kind == 1) return launch_brick<GM_FORCE_FUSED_U>(c, lo, hi, lo2, hi2);
     return launch_brick<GM_FORCE_FUSED>(c, lo, hi, lo2, hi2);

@@ -204,6 +204,23 @@ def test_slab_window_is_bounded_by_the_allocation():
 
 
 @pytest.mark.gpu
+def test_a_slab_rank_beyond_the_32_bit_list_offsets_is_refused():
+    """The brick sweeps address the neighbour lists with 32-bit byte offsets (24 groups of 2^k >= 8 * capacity bytes): a
+    context whose capacity does not fit (> 16.7 M particles) allocates no lists and runs the per-particle cell walk; a
+    SLAB rank cannot (its boundary / interior launches are brick launches) and says so instead of computing garbage."""
+    from sph_taichi_amd.distributed import SlabSolver, run_local_slabs
+    from sph_taichi_amd import _lib
+    sd = _slab_scenes()[0]
+    n = scenes.build(sd)[1].particle_max_num
+    s = SlabSolver(sd, 0, 1, device=0, capacity_factor=(1 << 24) / n + 64.0)
+    assert s.capacity > (1 << 24)
+    run_local_slabs([s], 1, initialize=True)
+    with pytest.raises(_lib.SphError, match="more slabs"):
+        run_local_slabs([s], 1)
+    s.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 3])
 def test_local_slabs_shape_matched_bodies(world, tmp_path):
     """Dynamic RigidBodies straddling the cut planes: per-rank sums + all-reduce reproduce the single-domain

@@ -135,8 +135,9 @@ enum SphOption {
 };
 #define SPH_VAR_GROUPS 1   /* density: all nine runs filtered first (masks in registers), hits emitted centre run / edge runs / corner
                               runs, each group by descending hit count */
-#define SPH_VAR_RING 2     /* density: hit masks to a per-lane LDS ring, ONE balanced emission loop per lane (measured: no gain
-                              over GROUPS with compiler-generated code, profiles/r03f_variants_partition_x_emission.json) */
+/* (bit 2 was SPH_VAR_RING, the per-lane LDS ring of hit masks with ONE balanced emission loop per lane: built, parity-green,
+   slower than GROUPS -- profiles/r03f_variants_partition_x_emission.json, DESIGN.md 4.5 -- and removed after commit 1bbd9b5;
+   a mask with that bit set is refused) */
 #define SPH_VAR_FORCE_BF 8 /* force sweep: branch-free fluid pair term, buffer addressing for list and gather */
 #define SPH_VAR_DEEP 16    /* list-reading sweeps: list entries loaded a whole round (3 pairs) before they are decoded */
 /* 0 = the baseline: run-by-run emission in the reference's (dx, dy) order, plain list loop in the force sweep.

@@ -647,10 +647,9 @@ __host__ __device__ constexpr bool mode_inline_physics() {
     return MODE == GM_DENSITY || MODE == GM_DENSITY_EOS || MODE == GM_DF_DENSITY;
 }
 
-template <int BX_, int BY_, int BZ_, int CAP_, int LISTCAP_, int RD_ = 0>
+template <int BX_, int BY_, int BZ_, int CAP_, int LISTCAP_>
 struct BrickCfg {
     static constexpr int BX = BX_, BY = BY_, BZ = BZ_, CAP = CAP_, LISTCAP = LISTCAP_;
-    static constexpr int RD = RD_;  // hit-mask ring slots per lane (SPH_VAR_RING; 0 = no ring)
     static constexpr int NCOL = (BX + 2) * (BY + 2);
     static constexpr int NCELL = BX * BY * BZ;  // target cells of a brick
     static constexpr int NZS = BZ + 3;  // cell-end entries per column (start + BZ+2 ends)
@@ -665,18 +664,15 @@ struct BrickCfg {
     static constexpr int off_cols(bool has_w) { return off_colg(has_w) + 64 * 4; }
     static constexpr int off_tg(bool has_w) { return off_cols(has_w) + 80 * 4; }
     static constexpr int off_toff(bool has_w) { return off_tg(has_w) + 64 * 4; }
-    // [NCELL][9] u32, filtering sweeps without a ring: the nine candidate runs of a target cell (column << 11 | first LDS slot | length << 16)
+    // [NCELL][9] u32, filtering sweeps: the nine candidate runs of a target cell (column << 11 | first LDS slot | length << 16)
     static constexpr int off_run(bool has_w) { return off_toff(has_w) + 80 * 4; }
-    static constexpr int off_tag(bool has_w) { return off_run(has_w) + (has_w && RD == 0 ? NCELL * 9 * 4 : 0); }  // [NCELL][16] u16: tag|base of the cell's chunk k
-    static constexpr int off_ring(bool has_w) { return off_tag(has_w) + (RD > 0 ? NCELL * 16 * 2 : 0); }  // [RD][TPB] u32 hit masks
-    static constexpr int bytes(bool has_w) { return off_ring(has_w) + RD * TPB * 4; }
+    static constexpr int bytes(bool has_w) { return off_run(has_w) + (has_w ? NCELL * 9 * 4 : 0); }
     static_assert(NCOL <= 32, "column id must fit 5 bits of a list entry");
     static_assert(CAP <= 2048, "LDS slot must fit 11 bits of a list entry");
     static_assert(CAP % 4 == 0, "the m_V array starts on a 16-byte boundary");
-    static_assert(RD <= 16 && NCELL <= 64, "ring bookkeeping: 4-bit chunk ids in two registers; one lane of wave 1 per cell");
     static_assert(LISTCAP < SPH_CNT_LIST_OVF && LISTCAP <= SPH_GLIST_ROWS, "gcnt is a byte; glist has SPH_GLIST_ROWS rows");
     static_assert(bytes(true) <= 40960, "filtering sweeps: at least four workgroups per CU (160 KiB LDS)");
-    static_assert(RD > 0 || bytes(false) <= 32768, "force sweep: five workgroups per CU (ring tiles belong to filtering sweeps only)");
+    static_assert(bytes(false) <= 32768, "force sweep: five workgroups per CU");
 };
 
 // The bricks of one sweep.  A brick is a BX x BY footprint of (x, y) cell columns times a run of z layers whose HEIGHT
@@ -718,8 +714,7 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                                                       unsigned char* __restrict__ gcnt, int cap, int list_cap, int lshift) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool HAS_W = !mode_reads_list<MODE>();
-    constexpr bool V_RING = (VAR & SPH_VAR_RING) != 0 && CFG::RD > 0 && mode_inline_physics<MODE>();
-    constexpr bool V_GROUPS = (VAR & SPH_VAR_GROUPS) != 0 && !V_RING && !mode_reads_list<MODE>();
+    constexpr bool V_GROUPS = (VAR & SPH_VAR_GROUPS) != 0 && !mode_reads_list<MODE>();
     constexpr bool V_BF = (VAR & SPH_VAR_FORCE_BF) != 0 && MODE == GM_FORCE_FUSED_U;
     constexpr bool V_DEEP = (VAR & SPH_VAR_DEEP) != 0 && mode_reads_list<MODE>();
     constexpr bool INLINE_PHYS = mode_inline_physics<MODE>();  // pair terms inside the emission loop
@@ -834,27 +829,6 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
         Bi_0 = d.vf[gi_0];
         Ei_0 = target_load_E<MODE>(d, gi_0);
         if (!mode_reads_list<MODE>()) key_0 = d.key[gi_0];  // (the cell's z layer: only the filter asks)
-    }
-
-    // SPH_VAR_RING: tag|base of every 32-candidate chunk of every target cell, in the order the filter walks them (nine
-    // column runs, a run in chunks of 32): one lane of wave 1 per cell.  A target finds its cell's row by
-    // (brick column, z layer); the emission loop looks a chunk up by its ordinal.
-    if (V_RING && !overflow && wave == 1 && lane < CFG::NCELL) {
-        const int colb = lane / CFG::BZ, zc = lane % CFG::BZ;
-        const int ix = cx0 + colb / CFG::BY, iy = cy0 + colb % CFG::BY, cz = cz0 + zc;
-        if (ix < cx1 && iy < cy1 && cz < cz1) {
-            const int klo = (cz > 0 ? cz - 1 : 0) - sz0, khi = (cz < d.nz - 1 ? cz + 1 : d.nz - 1) - sz0;
-            unsigned short* row = reinterpret_cast<unsigned short*>(smem + CFG::off_tag(HAS_W)) + lane * 16;
-            int kc = 0;
-            for (int r = 0; r < 9; ++r) {
-                const int nx = ix + r / 3 - 1, ny = iy + r % 3 - 1;
-                if (nx < 0 || nx >= d.nx || ny < 0 || ny >= d.ny) continue;
-                const int ncol = (nx - sx0) * ncy + (ny - sy0);
-                const int rel = -sColG[ncol];
-                const int lo = sCE[ncol * CFG::NZS + klo] + rel, hi = sCE[ncol * CFG::NZS + khi + 1] + rel;
-                for (int base = lo; base < hi && kc < 16; base += 32, ++kc) row[kc] = (unsigned short)(((unsigned)ncol << 11) | (unsigned)base);
-            }
-        }
     }
 
     // ---- step B: stage the shell's (x, y, z, m_V) records; all loads of a lane in flight together ----
@@ -1016,74 +990,6 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                     if (INLINE_PHYS && !(d.ablate & 32)) pair_term(base16 + (bit << 4));
                 }
             };
-            if (V_RING) {
-                // SPH_VAR_RING: the non-empty hit masks go to a per-lane ring in LDS (slot s of lane t at
-                // ring[s * TPB + t]: conflict-free whatever s each lane is at), the ordinals of their chunks to two
-                // registers of 4-bit fields; then ONE loop per lane takes a hit per trip from whatever mask the lane is
-                // at, refilling from the ring (next mask and its tag|base are fetched a mask ahead).  LDS is per-lane
-                // indexable where registers are not: the loop runs as many trips as the wave's busiest lane has hits
-                // (33 on the rest lattice, ~52 settled) instead of the sum over the runs of the per-run maxima (68 / 69
-                // with the group-sorted emission), every lane is at list row `trip` in every trip -- the u16 row
-                // stores of a wave fall into ONE 128-byte line per trip instead of one line per diverged lane -- and
-                // no mask lives in a register across the filter.
-                unsigned* const ring = reinterpret_cast<unsigned*>(smem + CFG::off_ring(HAS_W)) + tid;
-                const unsigned short* const tagrow = reinterpret_cast<const unsigned short*>(smem + CFG::off_tag(HAS_W)) +
-                                                     (((ix - cx0) * CFG::BY + (iy - cy0)) * CFG::BZ + (cz - cz0)) * 16;
-                unsigned ids_lo = 0, ids_hi = 0;
-                int w = 0, kc = 0;
-#pragma unroll
-                for (int r = 0; r < 9; ++r) {
-                    const int nx = ix + r / 3 - 1, ny = iy + r % 3 - 1;
-                    if (nx < 0 || nx >= d.nx || ny < 0 || ny >= d.ny) continue;
-                    const int ncol = (nx - sx0) * ncy + (ny - sy0);
-                    const int rel = -sColG[ncol];
-                    const int lo = sCE[ncol * CFG::NZS + klo] + rel, hi = sCE[ncol * CFG::NZS + khi + 1] + rel;
-                    for (int base = lo; base < hi; base += 32, ++kc) {
-                        const unsigned mask = filter_chunk(base, min(32, hi - base));
-                        if (mask == 0u) continue;
-                        if (kc < 16 && w < CFG::RD) {
-                            ring[w * TPB] = mask;
-                            const unsigned f = (unsigned)kc << ((unsigned)(w & 7) * 4u);
-                            if (w < 8) ids_lo |= f; else ids_hi |= f;
-                            ++w;
-                            cnt += __popc(mask);
-                        } else {  // a crowded neighbourhood (more than RD non-empty chunks): emitted on the spot
-                            emit_micro(mask, ((unsigned)ncol << 11) | (unsigned)base, (unsigned)base << 4);
-                        }
-                    }
-                }
-                // A trip that takes a mask's last hit requests the lane's next mask and its tag|base FIRST, so that they
-                // come back behind the pair term's own reads while that is being computed, and hands over at the bottom
-                // of the same trip.  The two reads and their wait are issued by hand: left to itself the compiler sinks
-                // the reads to their use (and waits there), and a `volatile` read becomes a flat load.  Nothing may touch
-                // m_ / tg_ between the reads and the wait (the compiler does not know they are in flight): they are
-                // defined and consumed inside one iteration, and tools/check_isa.py looks at the generated code.
-                const unsigned ring_a = (unsigned)(uintptr_t)(smem + CFG::off_ring(HAS_W)) + (unsigned)tid * 4u;
-                const unsigned tag_a = (unsigned)(uintptr_t)tagrow;
-                auto chunk_id = [&](int slot) -> unsigned { return ((slot < 8 ? ids_lo : ids_hi) >> ((unsigned)(slot & 7) * 4u)) & 15u; };
-                unsigned cur = w > 0 ? ring[0] : 0u, cb = tagrow[chunk_id(0)];
-                int taken = 1;  // masks taken so far = ring slot of the next one
-                while (cur != 0u) {
-                    const unsigned bit = (unsigned)__ffs((int)cur) - 1u;
-                    const unsigned rest = cur & (cur - 1u);
-                    unsigned m_ = 0u, tg_ = 0u;
-                    if (rest == 0u) {
-                        const int tk = min(taken, CFG::RD - 1);  // (always a valid slot; beyond the lane's last mask the value is dropped)
-                        asm volatile("ds_read_b32 %0, %2\n\tds_read_u16 %1, %3"
-                                     : "=&v"(m_), "=&v"(tg_) : "v"(ring_a + (unsigned)tk * (unsigned)(TPB * 4)), "v"(tag_a + (chunk_id(tk) << 1)));
-                    }
-                    if (!(d.ablate & 2)) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(cb + bit), lrs, (int)(voff ^ lflip), 0, 0);
-                    voff = __builtin_elementwise_add_sat(voff, 2u) | lmask;
-                    if (!(d.ablate & 32)) pair_term((((cb & 2047u) + bit) << 4));
-                    cur = rest;
-                    if (rest == 0u) {
-                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(m_), "+v"(tg_));
-                        cur = taken < w ? m_ : 0u;
-                        cb = tg_;
-                        ++taken;
-                    }
-                }
-            } else
             if (V_GROUPS) {
                 // SPH_VAR_GROUPS (default): all nine runs are filtered first (their first 32 candidates: one mask and
                 // one tag|base per run stay in registers; longer runs emit their further chunks at once), then every
@@ -1339,9 +1245,8 @@ __global__ __launch_bounds__(TPB) void k_eos(DevView d) {
 // host-side launchers
 // ---------------------------------------------------------------------------
 typedef BrickCfg<4, 2, 4, 1792, 95> Cfg0;  // 4x2 columns x up to 4 layers: 1152 candidates / 256 targets at rest
-typedef BrickCfg<4, 2, 4, 1392, 95, 10> CfgR;  // the same bricks with the hit-mask ring of SPH_VAR_RING beside a smaller tile (k_brick_list cuts for it)
 // shell records a brick may hold (the cut rule of k_brick_list): the smallest tile among the kernels of the step
-static int brick_smax(const SphContext* c) { return (c->opt_variant & SPH_VAR_RING) ? CfgR::CAP : Cfg0::CAP; }
+static int brick_smax(const SphContext*) { return Cfg0::CAP; }
 
 template <int MODE>
 static int launch_simple(SphContext* c, const int* list, int n) {
@@ -1457,7 +1362,6 @@ static int launch_brick(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, in
     // SPH_OPT_KERNEL_VARIANT: the instances of the two sweeps of the fused WCSPH step (include/sph_hip.h)
     const int var = c->opt_variant;
     if constexpr (MODE == GM_DENSITY_EOS) {
-        if (var & SPH_VAR_RING) return launch_brick_cfg<MODE, CfgR, SPH_VAR_RING>(c, lo, hi, lo2, hi2);
         if (var & SPH_VAR_GROUPS) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS>(c, lo, hi, lo2, hi2);
     }
     if constexpr (MODE == GM_FORCE_FUSED_U) {
@@ -1506,15 +1410,9 @@ static int launch_df(SphContext* c) {
         if (mode_is_df_vdiv<MODE>()) c->k_kind = 0;  // density_adv changes, the walk does not refresh k_j
         return launch_simple<MODE>(c, nullptr, c->N);
     }
-    // SPH_OPT_KERNEL_VARIANT: the list-writing density sweep can take the ring emission; the group-sorted emission and
-    // the early entry loads of SPH_VAR_DEEP do nothing measurable for these sweeps (DFSPH step 3.46 vs 3.51 ms with
-    // DEEP, profiles/r02g: their pair terms gather 4 bytes, not a 16-byte record).
-    int rc;
-    if constexpr (mode_writes_list<MODE>()) {
-        if (c->opt_variant & SPH_VAR_RING) rc = launch_brick_cfg<MODE, CfgR, SPH_VAR_RING>(c);
-        else rc = launch_brick_cfg<MODE, Cfg0>(c);
-    } else
-        rc = launch_brick_cfg<MODE, Cfg0>(c);
+    // (the group-sorted emission and the early entry loads of SPH_VAR_DEEP do nothing measurable for these sweeps: DFSPH
+    // step 3.46 vs 3.51 ms with DEEP, profiles/r02g -- their pair terms gather 4 bytes, not a 16-byte record)
+    int rc = launch_brick_cfg<MODE, Cfg0>(c);
     if (!rc && mode_writes_list<MODE>()) { c->lists_valid = true; c->gcnt_written = true; c->stg_kind = 2; c->k_kind = 0; }
     if (!rc && MODE == GM_DF_DENSITY_CHANGE) c->k_kind = 1;
     if (!rc && MODE == GM_DF_DENSITY_ADV) c->k_kind = 2;

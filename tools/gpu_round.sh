@@ -5,7 +5,7 @@
 #     pmc      : rocprofv3 PMC passes, from rest and settled -> gpurun_out/<tag>/pmc_traffic.json (+ summaries)
 #     kstats   : rocprofv3 kernel-trace stats of the default bench line's two states
 #     bench    : the default bench line + the other workloads
-#     variants : A/B table  partition (adaptive / fixed bricks) x emission (group-sorted / ring)
+#     variants : A/B table  partition (adaptive / fixed bricks) x emission (group-sorted / baseline)
 #     native   : kernel trace of the one-rank native RCCL worker
 TAG=${1:-round}; shift
 PARTS=${*:-tests pmc kstats bench variants}
@@ -42,7 +42,7 @@ if has bench; then
   for f in driver_args c1_dambreak_262k c2_dragon_bath c3_armadillo_equiv c1_developed dfsph_c3p; do python -c "import json;d=json.load(open('$OUT/bench_$f.json'));print('$f',d['value'],d['ms_per_step'],d['breakdown_ms'])"; done
 fi
 if has variants; then
-  timeout 600 python tools/variant_sweep.py --variants 25,26,0 --shapes 1,0 --steps 60 --settled-steps 80 --out $OUT/variants_partition_x_emission.json > $OUT/variants.log 2>&1
+  timeout 600 python tools/variant_sweep.py --variants 25,0 --shapes 1,0 --steps 60 --settled-steps 80 --out $OUT/variants_partition_x_emission.json > $OUT/variants.log 2>&1
   grep -v "^$" $OUT/variants.log | grep -v amdgpu | tail -n 10
 fi
 if has native; then

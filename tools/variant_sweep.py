@@ -43,7 +43,7 @@ def timed(ps, solver, lib, steps, warmup):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="c3p_uniform_1.75M")
-    ap.add_argument("--variants", default="25,26,0,1,24")
+    ap.add_argument("--variants", default="25,0,1,24")
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--settle", type=int, default=2000)
     ap.add_argument("--settled-steps", type=int, default=60)

@@ -27,7 +27,15 @@ The JSON line also carries
                   algorithm with OpenMP; timing build -O3 -march=native) on the CPUs
                   this container may use (cgroup quota), median of three bounded
                   samples of the same workload;
-  neighbourhood : list lengths / cell occupancy of the last density sweep.
+  neighbourhood : list lengths / cell occupancy of the last density sweep;
+  reps, first_rep: the contract's block (W untimed + exactly K timed steps from the initial lattice) repeated
+                  from the restored initial state until --min-seconds of timed steps have run: value /
+                  ms_per_step / breakdown_ms are the means;
+  preheat_ms, cold_block: every block starts behind that many ms of unrelated GPU load (the clock ramp after
+                  the host-side set-up is 8 % of a 25-step block); cold_block = one block without it;
+  settled       : the same box after --settled-after further steps (what a long run sees), with its own value,
+                  ms_per_step, breakdown_ms, neighbourhood, roofline_kernels, roofline_step;
+  roofline_kernels, roofline_step: both sweeps of each state (bytes, event time, counter traffic, VALU share).
 --settle K times a developed flow, --variant M an A/B kernel instance, --ablate the
 section table of DESIGN.md section 4.4 (stderr).
 """

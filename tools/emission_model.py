@@ -92,7 +92,13 @@ def analyse(x, h, label, BX=4, BY=2, BZ=4, margin=1.0002, sort_cells=False):
                 t = np.array(t, np.int64)
                 if len(t) < 64:
                     continue
-                if sort_cells:      # lanes assigned cell by cell in order of the cell's candidate count (longest runs first)
+                if sort_cells == "octant":   # lanes assigned by the octant of the target inside its cell (then by cell)
+                    oc = (frac[t, 0] >= 0.5) * 4 + (frac[t, 1] >= 0.5) * 2 + (frac[t, 2] >= 0.5) * 1
+                    t = t[np.argsort(oc, kind="stable")]
+                elif sort_cells == "octant27":   # finer: thirds of the cell in every axis
+                    oc = np.minimum((frac[t, 0] * 3).astype(int), 2) * 9 + np.minimum((frac[t, 1] * 3).astype(int), 2) * 3 + np.minimum((frac[t, 2] * 3).astype(int), 2)
+                    t = t[np.argsort(oc, kind="stable")]
+                elif sort_cells:      # lanes assigned cell by cell in order of the cell's candidate count (longest runs first)
                     work = [int(rlen[beg[c]].sum()) if cnt[c] else 0 for c in cells]
                     order_c = sorted(range(len(cells)), key=lambda q: -work[q])
                     t = np.array([p_ for q in order_c for p_ in range(beg[cells[q]], end[cells[q]])], np.int64)
@@ -154,6 +160,8 @@ def main():
     if a.steps:
         analyse(x1.astype(np.float64), h, f"after {a.steps} steps")
         analyse(x1.astype(np.float64), h, f"after {a.steps} steps, lanes by cell workload", sort_cells=True)
+        analyse(x1.astype(np.float64), h, f"after {a.steps} steps, lanes by octant of the target in its cell", sort_cells="octant")
+        analyse(x1.astype(np.float64), h, f"after {a.steps} steps, lanes by thirds of the cell (27 classes)", sort_cells="octant27")
 
 
 if __name__ == "__main__":

@@ -1017,7 +1017,7 @@ def run_slab_bench(args, rank, world, local_rank):
         transport = TorchTransport(torch.device("cuda", local_rank))
     s.attach(transport)
     s.initialize()
-    from bench import gpu_preheat  # noqa: E402  (clock ramp after the host-side set-up: see its docstring)
+    from bench import gpu_preheat, _HEAT  # noqa: E402  (clock ramp after the host-side set-up: see its docstring)
     gpu_preheat(local_rank, float(getattr(args, "preheat_ms", 0.0)))
     s.step(args.warmup)
     s.ps.sync()
@@ -1072,7 +1072,7 @@ def run_slab_bench(args, rank, world, local_rank):
         "value": round(steps_per_s * n_global / REF_PARTICLES, 3), "unit": "steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "preheat_ms": float(getattr(args, "preheat_ms", 0.0)),
+        "preheat_ms": 0.0 if _HEAT.get("broken") else float(getattr(args, "preheat_ms", 0.0)),
         "config": {"workload": f"c3p_tiled_x{world}_{246 * world}x74x96", "particles": n_global,
                    "particles_owned_sum": int(own.item()), "cuts": s.cuts, "halo_layers": s.halo,
                    "sent_records_per_step": round(s.stats["sent"] / max(args.steps + args.warmup + 1, 1), 1),

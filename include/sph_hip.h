@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SPH_ABI_VERSION 3
+#define SPH_ABI_VERSION 4
 
 typedef struct SphContext SphContext;
 
@@ -131,7 +131,14 @@ enum SphOption {
                                   that ghost velocities can be refreshed record for record */,
     SPH_OPT_KERNEL_VARIANT = 10 /* A/B switch for the brick sweeps of the fused WCSPH step: bit mask of
                                   SPH_VAR_* below.  Every combination computes the same sums (list order and rounding
-                                  apart); -1 = the library's default */
+                                  apart); -1 = the library's default */,
+    SPH_OPT_RIGID_BATCH = 11   /* 1 (default) = solve_rigid_body() (sph_base.py:247-260) of ALL dynamic bodies in three launches
+                                  inside sph_step / sph_dfsph_step, the per-body solid wall passes replayed per particle;
+                                  0 = body by body (4 launches each).  Same results bit for bit. */,
+    SPH_OPT_EXACT_MATH = 12    /* A/B of the fast-math choice (never the default): 1 = the brick sweeps of the fused WCSPH step
+                                  (density + EOS, force) evaluate r.norm(), r / (|r| h), x / y with IEEE sqrt and divide
+                                  as the reference's f32 expressions do, instead of v_rsq_f32 / v_rcp_f32 (~1 ulp).
+                                  profiles/r04_parity_fastmath_ab.json holds the two builds side by side. */
 };
 #define SPH_VAR_GROUPS 1   /* density: all nine runs filtered first (masks in registers), hits emitted centre run / edge runs / corner
                               runs, each group by descending hit count */
@@ -309,6 +316,9 @@ int32_t sph_upload_rest_positions(SphContext* ctx, const int32_t* pid, const flo
  * does next.  sph_comm_halo_time: accumulated duration of the payload exchanges on the communication stream. */
 typedef struct SphComm SphComm;
 const char* sph_comm_last_error(void);
+/* 0 if librccl (or the library named by SPH_RCCL_LIB) can be opened and exports what this file binds: lets the ranks of a
+ * job agree on the transport BEFORE anybody enters the collective sph_comm_create. */
+int32_t sph_comm_available(void);
 int32_t sph_comm_unique_id(uint8_t* out128);
 int32_t sph_comm_create(SphContext* ctx, const uint8_t* id128, int32_t rank, int32_t world, SphComm** out);
 int32_t sph_comm_destroy(SphComm* comm);

@@ -167,6 +167,21 @@ def main():
               color=[200, 100, 50])
     d5["FluidBlocks"].append(f1)
     jobs["ref_two_fluids"] = (d5, 8)
+    # The HIGH faces (VERDICT r03 "missing" #5).  The reference flattens neighbour cells without a bounds check
+    # (particle_system.py:381-383): for a particle in the LAST y layer, cy + 1 = n_y aliases into cell (cx + 1, 0, cz), in
+    # the last z layer cz + 1 = n_z into (cx, cy + 1, 0) -- far-away real cells whose particles then fail the distance
+    # test -- where the oracle and the HIP path skip the cell.  A wall-clamped particle sits exactly in the last layer
+    # ((size - pad) / h = n - 1), so a block thrown at the (+y, +z) edge keeps particles there for many steps.  The +x
+    # face is left alone: there the reference reads out of bounds (`ti.oob_reads` asserts that no run does).
+    d7 = scenes.fluid_only(counts=(6, 7, 5), start=(0.2, 0.436, 0.476), velocity=(1.0, 8.0, 6.0), domain_end=(0.6, 0.6, 0.6))
+    jobs["ref_high_faces_fluid"] = (d7, 14)
+    # ... and a shape-matched dynamic body (its particles are clamped by enforce_boundary_3D(solid), sph_base.py:260) next
+    # to the fluid: solids in the last layers too, boundary volumes and the coupling scatter across the aliased lookups
+    d8 = scenes.fluid_only(counts=(8, 6, 6), start=(0.15, 0.455, 0.455), velocity=(0.0, 7.0, 5.0), domain_end=(0.6, 0.6, 0.6))
+    d8["RigidBodies"] = [{"objectId": 1, "geometryFile": "tests/golden/cube_0p1.obj", "translation": [0.315, 0.45, 0.45],
+                          "rotationAxis": [0, 0, 1], "rotationAngle": 0, "scale": [1, 1, 1], "velocity": [0.2, 7.0, 5.0],
+                          "density": 600.0, "color": [255, 255, 255], "isDynamic": True}]
+    jobs["ref_high_faces_rigid"] = (d8, 14)
     d6 = copy.deepcopy(d5)                                   # ... and under DFSPH (the general *_ITER sweeps)
     d6["Configuration"]["simulationMethod"] = 4
     d6["Configuration"]["timeStepSize"] = 0.002

@@ -56,11 +56,12 @@ F_OBJECT_ID, F_X, F_X_0, F_V, F_ACCELERATION, F_M_V, F_M, F_DENSITY, F_PRESSURE,
     F_IS_DYNAMIC, F_GRID_IDS, F_GRID_PARTICLES_NUM, F_PID, F_RIGID_REST_CM, F_DFSPH_FACTOR, F_DENSITY_ADV = range(18)
 # enum SphOption
 OPT_GATHER_IMPL, OPT_TIMING, OPT_FUSED_STEP, OPT_BRICK_SHAPE, OPT_NO_DYNAMIC_SOLIDS, OPT_DEBUG_ABLATE, \
-    OPT_SLAB_DROP_OUTSIDE, OPT_UNIFORM_FLUID, OPT_UNIFORM_FLUID_STATE, OPT_SORT_BY_PID, OPT_KERNEL_VARIANT = range(11)
+    OPT_SLAB_DROP_OUTSIDE, OPT_UNIFORM_FLUID, OPT_UNIFORM_FLUID_STATE, OPT_SORT_BY_PID, OPT_KERNEL_VARIANT, \
+    OPT_RIGID_BATCH, OPT_EXACT_MATH = range(13)
 VAR_GROUPS, VAR_FORCE_BF, VAR_DEEP = 1, 8, 16
 VAR_DEFAULT = VAR_GROUPS | VAR_FORCE_BF | VAR_DEEP
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/sph_hip.h declares: (name, restype, argtypes)
 _ctx = C.c_void_p
@@ -136,6 +137,7 @@ SYMBOLS = [
     ("sph_dfsph_compute_density_error_range", C.c_int32, [_ctx, C.c_float, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
     ("sph_copy_velocity_records", C.c_int32, [_ctx, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]),
     ("sph_comm_last_error", C.c_char_p, []),
+    ("sph_comm_available", C.c_int32, []),
     ("sph_comm_unique_id", C.c_int32, [C.c_void_p]),
     ("sph_comm_create", C.c_int32, [_ctx, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     ("sph_comm_destroy", C.c_int32, [C.c_void_p]),

@@ -124,6 +124,8 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     c->opt_fused = 1;
     c->opt_timing = 0;
     c->opt_brick_shape = 0;
+    c->opt_rigid_batch = 1;
+    c->opt_exact_math = 0;
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -243,6 +245,8 @@ int32_t sph_set_option(SphContext* c, int32_t option, int32_t value) {
         case SPH_OPT_DEBUG_ABLATE: c->opt_ablate = value; return 0;
         case SPH_OPT_SLAB_DROP_OUTSIDE: c->opt_drop_outside = value ? 1 : 0; c->uniform_state = -1; return 0;
         case SPH_OPT_SORT_BY_PID: c->opt_sort_by_pid = value ? 1 : 0; return 0;
+        case SPH_OPT_RIGID_BATCH: c->opt_rigid_batch = value ? 1 : 0; return 0;
+        case SPH_OPT_EXACT_MATH: c->opt_exact_math = value ? 1 : 0; sph_invalidate_lists(c); return 0;
         case SPH_OPT_KERNEL_VARIANT:
             if (value < -1 || value > 31 || (value > 0 && (value & 6))) return sph_fail(c, SPH_E_INVALID, "kernel variant must be -1 (default) or a mask of SPH_VAR_*");
             c->opt_variant = value < 0 ? SPH_VAR_DEFAULT : value;
@@ -265,6 +269,8 @@ int32_t sph_get_option(const SphContext* c, int32_t option, int32_t* value) {
         case SPH_OPT_SLAB_DROP_OUTSIDE: *value = c->opt_drop_outside; return 0;
         case SPH_OPT_UNIFORM_FLUID: *value = c->opt_uniform; return 0;
         case SPH_OPT_SORT_BY_PID: *value = c->opt_sort_by_pid; return 0;
+        case SPH_OPT_RIGID_BATCH: *value = c->opt_rigid_batch; return 0;
+        case SPH_OPT_EXACT_MATH: *value = c->opt_exact_math; return 0;
         case SPH_OPT_KERNEL_VARIANT: *value = c->opt_variant; return 0;
         case SPH_OPT_UNIFORM_FLUID_STATE: *value = c->uniform_state; return 0;
     }
@@ -571,12 +577,7 @@ static int step_sweeps(SphContext* c, hipEvent_t* ev, const int32_t* dynamic_ids
     rc = fused_advect ? sphk_advect_dyn_list(c) : sphk_advect(c, true);
     if (rc) return rc;
     // solve_rigid_body()                                   sph_base.py:247-260
-    if (c->n_dyn_host > 0)
-        for (int k = 0; k < n_dynamic; ++k) {
-            rc = sphk_rigid_solve(c, dynamic_ids[k]);
-            rc = rc ? rc : sphk_enforce_boundary(c, SPH_MATERIAL_SOLID);
-            if (rc) return rc;
-        }
+    if (c->n_dyn_host > 0) { rc = sphk_rigid_solve_all(c, dynamic_ids, n_dynamic); if (rc) return rc; }
     return 0;
 }
 
@@ -1109,12 +1110,7 @@ int32_t sph_dfsph_step(SphContext* c, int32_t n_steps, const int32_t* dynamic_id
         if (timing) SPH_HIP(c, hipEventRecord(ev[3], c->stream));
         rc = sphk_df_advect(c, true);                                // advect + enforce_boundary_3D(fluid)
         if (rc) return rc;
-        if (c->n_dyn_host > 0)                                       // solve_rigid_body()  sph_base.py:247-260
-            for (int k = 0; k < n_dynamic; ++k) {
-                rc = sphk_rigid_solve(c, dynamic_ids[k]);
-                rc = rc ? rc : sphk_enforce_boundary(c, SPH_MATERIAL_SOLID);
-                if (rc) return rc;
-            }
+        if (c->n_dyn_host > 0) { rc = sphk_rigid_solve_all(c, dynamic_ids, n_dynamic); if (rc) return rc; }  // solve_rigid_body()  sph_base.py:247-260
         if (timing) { SPH_HIP(c, hipEventRecord(ev[4], c->stream)); c->ev_used++; }
         c->df_stats.steps++;
     }

@@ -13,7 +13,21 @@
 #include "sph_internal.h"
 
 #include <dlfcn.h>
+
+// The few RCCL declarations this file needs, spelled out: the library is opened with dlopen, and a single-GPU build of
+// libsph_hip.so should not need the RCCL headers either.  Values as in <rccl/rccl.h> (checked against it below whenever
+// that header is on the include path).
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+static_assert(sizeof(ncclUniqueId) == 128 && ncclSuccess == 0 && ncclUint8 == 1 && ncclInt32 == 2 && ncclInt64 == 4 &&
+              ncclFloat64 == 8 && ncclSum == 0, "the local RCCL declarations below no longer match <rccl/rccl.h>");
+#else
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclUint8 = 1, ncclInt32 = 2, ncclInt64 = 4, ncclFloat64 = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+#endif
 
 struct RcclApi {
     void* handle;
@@ -33,14 +47,20 @@ static thread_local char g_comm_err[256] = "";
 
 static int rccl_load() {
     if (g_rccl.handle) return 0;
+    // SPH_RCCL_LIB (tests): open THIS library instead -- tests/fake_rccl/libfake_rccl.so, a stand-in that lets several
+    // processes sharing one GPU run the exchange (RCCL itself refuses two ranks on a device).  Never a silent fallback:
+    // if the variable is set and the library does not load, that is the error.
+    const char* forced = getenv("SPH_RCCL_LIB");
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     void* h = nullptr;
-    for (const char* n : names) {
-        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (h) break;
-    }
+    if (forced && forced[0]) h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    else
+        for (const char* n : names) {
+            h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (h) break;
+        }
     if (!h) {
-        snprintf(g_comm_err, sizeof(g_comm_err), "librccl not found (%s)", dlerror());
+        snprintf(g_comm_err, sizeof(g_comm_err), "%s not found (%s)", forced && forced[0] ? forced : "librccl", dlerror());
         return SPH_E_STATE;
     }
     RcclApi a = {};
@@ -66,6 +86,7 @@ struct SphComm {
     SphContext* ctx;
     ncclComm_t comm;
     int rank, world;
+    int device;             // (kept here: sph_comm_destroy may run after the context is gone)
     hipStream_t stream;     // communication stream (beside the context's main and side streams)
     hipEvent_t ev_in;       // main stream -> communication stream
     hipEvent_t ev_done;     // communication stream -> main stream
@@ -89,10 +110,22 @@ struct SphComm {
             return SPH_E_STATE;                                                                  \
         }                                                                                        \
     } while (0)
+// inside ncclGroupStart .. ncclGroupEnd: a failing call must not leave the group open
+#define SPH_NCCL_G(c, expr)                                                                      \
+    do {                                                                                         \
+        ncclResult_t r__ = (expr);                                                               \
+        if (r__ != ncclSuccess) {                                                                \
+            snprintf((c)->err, sizeof((c)->err), "%s: %s", #expr, g_rccl.GetErrorString(r__));    \
+            (void)g_rccl.GroupEnd();                                                             \
+            return SPH_E_STATE;                                                                  \
+        }                                                                                        \
+    } while (0)
 
 extern "C" {
 
 const char* sph_comm_last_error(void) { return g_comm_err; }
+
+int32_t sph_comm_available(void) { return rccl_load(); }
 
 int32_t sph_comm_unique_id(uint8_t* out128) {
     if (!out128) return SPH_E_INVALID;
@@ -111,7 +144,7 @@ int32_t sph_comm_unique_id(uint8_t* out128) {
 
 int32_t sph_comm_destroy(SphComm* m) {
     if (!m) return 0;
-    if (m->ctx) (void)hipSetDevice(m->ctx->device);
+    (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     if (m->comm) (void)g_rccl.CommDestroy(m->comm);
     for (hipEvent_t e : {m->ev_in, m->ev_done, m->ev_cnt, m->ev_t0, m->ev_t1})
@@ -131,7 +164,7 @@ int32_t sph_comm_create(SphContext* c, const uint8_t* id128, int32_t rank, int32
     SPH_HIP(c, hipSetDevice(c->device));
     SphComm* m = new SphComm();
     memset(m, 0, sizeof(*m));
-    m->ctx = c; m->rank = rank; m->world = world;
+    m->ctx = c; m->rank = rank; m->world = world; m->device = c->device;
     ncclUniqueId id;
     memcpy(&id, id128, 128);
     ncclResult_t r = g_rccl.CommInitRank(&m->comm, world, id, rank);
@@ -182,12 +215,12 @@ int32_t sph_slab_announce(SphContext* c, SphComm* m, int32_t left, int32_t right
     SPH_HIP(c, hipMemsetAsync(m->d_cnt + 2, 0, 2 * sizeof(int), m->stream));
     SPH_NCCL(c, g_rccl.GroupStart());
     if (left >= 0) {
-        SPH_NCCL(c, g_rccl.Send(m->d_cnt + 0, 1, ncclInt32, left, m->comm, m->stream));
-        SPH_NCCL(c, g_rccl.Recv(m->d_cnt + 2, 1, ncclInt32, left, m->comm, m->stream));
+        SPH_NCCL_G(c, g_rccl.Send(m->d_cnt + 0, 1, ncclInt32, left, m->comm, m->stream));
+        SPH_NCCL_G(c, g_rccl.Recv(m->d_cnt + 2, 1, ncclInt32, left, m->comm, m->stream));
     }
     if (right >= 0) {
-        SPH_NCCL(c, g_rccl.Send(m->d_cnt + 1, 1, ncclInt32, right, m->comm, m->stream));
-        SPH_NCCL(c, g_rccl.Recv(m->d_cnt + 3, 1, ncclInt32, right, m->comm, m->stream));
+        SPH_NCCL_G(c, g_rccl.Send(m->d_cnt + 1, 1, ncclInt32, right, m->comm, m->stream));
+        SPH_NCCL_G(c, g_rccl.Recv(m->d_cnt + 3, 1, ncclInt32, right, m->comm, m->stream));
     }
     SPH_NCCL(c, g_rccl.GroupEnd());
     SPH_HIP(c, hipMemcpyAsync(m->h_cnt, m->d_cnt + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, m->stream));
@@ -239,12 +272,12 @@ int32_t sph_slab_exchange(SphContext* c, SphComm* m, int32_t left, int32_t right
     SPH_HIP(c, hipEventRecord(m->ev_t0, m->stream));
     SPH_NCCL(c, g_rccl.GroupStart());
     if (left >= 0) {
-        if (n_to_left > 0) SPH_NCCL(c, g_rccl.Send(send_left, (size_t)n_to_left * rec, ncclUint8, left, m->comm, m->stream));
-        if (n_from_left > 0) SPH_NCCL(c, g_rccl.Recv(recv_left, (size_t)n_from_left * rec, ncclUint8, left, m->comm, m->stream));
+        if (n_to_left > 0) SPH_NCCL_G(c, g_rccl.Send(send_left, (size_t)n_to_left * rec, ncclUint8, left, m->comm, m->stream));
+        if (n_from_left > 0) SPH_NCCL_G(c, g_rccl.Recv(recv_left, (size_t)n_from_left * rec, ncclUint8, left, m->comm, m->stream));
     }
     if (right >= 0) {
-        if (n_to_right > 0) SPH_NCCL(c, g_rccl.Send(send_right, (size_t)n_to_right * rec, ncclUint8, right, m->comm, m->stream));
-        if (n_from_right > 0) SPH_NCCL(c, g_rccl.Recv(recv_right, (size_t)n_from_right * rec, ncclUint8, right, m->comm, m->stream));
+        if (n_to_right > 0) SPH_NCCL_G(c, g_rccl.Send(send_right, (size_t)n_to_right * rec, ncclUint8, right, m->comm, m->stream));
+        if (n_from_right > 0) SPH_NCCL_G(c, g_rccl.Recv(recv_right, (size_t)n_from_right * rec, ncclUint8, right, m->comm, m->stream));
     }
     SPH_NCCL(c, g_rccl.GroupEnd());
     SPH_HIP(c, hipEventRecord(m->ev_t1, m->stream));
@@ -266,12 +299,12 @@ int32_t sph_comm_swap(SphContext* c, SphComm* m, int32_t left, int32_t right, co
     SPH_HIP(c, hipStreamWaitEvent(m->stream, m->ev_in, 0));
     SPH_NCCL(c, g_rccl.GroupStart());
     if (left >= 0) {
-        if (bytes_to_left > 0) SPH_NCCL(c, g_rccl.Send(send_left, (size_t)bytes_to_left, ncclUint8, left, m->comm, m->stream));
-        if (bytes_from_left > 0) SPH_NCCL(c, g_rccl.Recv(recv_left, (size_t)bytes_from_left, ncclUint8, left, m->comm, m->stream));
+        if (bytes_to_left > 0) SPH_NCCL_G(c, g_rccl.Send(send_left, (size_t)bytes_to_left, ncclUint8, left, m->comm, m->stream));
+        if (bytes_from_left > 0) SPH_NCCL_G(c, g_rccl.Recv(recv_left, (size_t)bytes_from_left, ncclUint8, left, m->comm, m->stream));
     }
     if (right >= 0) {
-        if (bytes_to_right > 0) SPH_NCCL(c, g_rccl.Send(send_right, (size_t)bytes_to_right, ncclUint8, right, m->comm, m->stream));
-        if (bytes_from_right > 0) SPH_NCCL(c, g_rccl.Recv(recv_right, (size_t)bytes_from_right, ncclUint8, right, m->comm, m->stream));
+        if (bytes_to_right > 0) SPH_NCCL_G(c, g_rccl.Send(send_right, (size_t)bytes_to_right, ncclUint8, right, m->comm, m->stream));
+        if (bytes_from_right > 0) SPH_NCCL_G(c, g_rccl.Recv(recv_right, (size_t)bytes_from_right, ncclUint8, right, m->comm, m->stream));
     }
     SPH_NCCL(c, g_rccl.GroupEnd());
     SPH_HIP(c, hipEventRecord(m->ev_done, m->stream));

@@ -433,6 +433,169 @@ __global__ __launch_bounds__(TPB) void k_rigid_apply(DevView d, const int* __res
     d.xm[i] = xm;
 }
 
+// ---- solve_rigid_body() for ALL dynamic bodies in three launches (sph_base.py:247-260) ----
+// The reference runs, body by body, solve_constraints(body) and then enforce_boundary_3D(solid) over EVERY dynamic solid
+// particle.  The wall pass is a pure function of one particle's (x, v) -- but not idempotent: it clamps the position once,
+// yet a particle sitting exactly on a LOW wall (x == padding satisfies `pos <= padding`, sph_base.py:158) has its velocity
+// reflected again by every later pass.  So the passes cannot be merged into one; they can be REPLAYED per particle: a
+// particle of the b-th body (0-based) has seen b passes when its body is solved and sees n - b afterwards; any other
+// dynamic solid sees all n.  The kernels below apply those passes in registers, so the three phases (sums, A, apply)
+// run once over the list of dynamic rigid particles with per-body rows of partial sums, instead of 4 launches per body,
+// and give bit for bit what the sequence gives (the sums are exact fixed-point integers, the per-particle terms the
+// same expressions): tests/test_gpu_parity.py::test_batched_rigid_solve_equals_the_body_by_body_sequence.
+#define SPH_MAX_BATCH_BODIES 16
+struct BodyIds { int n; int id[SPH_MAX_BATCH_BODIES]; };
+
+__device__ __forceinline__ int body_slot(const BodyIds& b, int object_id) {
+    int s = -1;
+#pragma unroll
+    for (int k = 0; k < SPH_MAX_BATCH_BODIES; ++k)
+        if (k < b.n && b.id[k] == object_id) s = k;
+    return s;
+}
+__device__ __forceinline__ void wall_passes(const DevView& d, const float hi[3], float4& xm, float4& vf, int passes) {
+    for (int p = 0; p < passes; ++p) wall_collide(d, hi, xm, vf);
+}
+
+// block-wide sum of NV values per thread -> part[blockIdx][off + k] of one body's row block; callable in a loop
+template <int NV>
+__device__ __forceinline__ void block_store_partials_at(const fx_t (&s)[NV], fx_t* __restrict__ part_body, int off, fx_t (*red)[16]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const fx_t w = wave_sum(s[k]);
+        if (lane == 0) red[wave][k] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        fx_t t = 0;
+#pragma unroll
+        for (int w = 0; w < TPB / 64; ++w) t += red[w][threadIdx.x];
+        part_body[(size_t)blockIdx.x * RIGID_PART + off + threadIdx.x] = t;
+    }
+    __syncthreads();
+}
+
+// totals of components [0, nv) of every body's partial rows -> s_tot[body][k] (wave w takes bodies w, w + 4, ...)
+__device__ __forceinline__ void sum_partials_all(const DevView& d, const fx_t* __restrict__ part, int nblk, int nbodies, int nv,
+                                                 double (*s_tot)[16]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int b = wave; b < nbodies; b += TPB / 64) {
+        const fx_t* pb = part + (size_t)b * nblk * RIGID_PART;
+        for (int k = 0; k < nv; ++k) {
+            fx_t t = 0;
+            for (int bIdx = lane; bIdx < nblk; bIdx += 64) t += pb[(size_t)bIdx * RIGID_PART + k];
+            t = wave_sum(t);
+            if (lane == 0) s_tot[b][k] = (double)t / d.fx_scale;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(TPB) void k_rigid_sum_all(DevView d, WallHi hi, const int* __restrict__ list, int n, BodyIds ids,
+                                                       fx_t* __restrict__ part, int nblk) {
+    __shared__ fx_t red[TPB / 64][16];
+    const int tix = blockIdx.x * TPB + threadIdx.x;
+    int slot = -1;
+    fx_t v[4] = {0, 0, 0, 0};
+    if (tix < n) {
+        const int i = list[tix];
+        float4 vf = d.vf[i];
+        const int fl = __float_as_int(vf.w);
+        if (sph_is_dynamic_rigid(fl) && (slot = body_slot(ids, sph_flags_object(fl))) >= 0) {
+            float4 xm = d.xm[i];
+            wall_passes(d, hi.v, xm, vf, slot);
+            const float mass = d.m_V0 * d.aux[i].y;
+            v[0] = to_fx(d, mass); v[1] = to_fx(d, (double)(mass * xm.x)); v[2] = to_fx(d, (double)(mass * xm.y)); v[3] = to_fx(d, (double)(mass * xm.z));
+        }
+    }
+    for (int b = 0; b < ids.n; ++b) {
+        const fx_t s[4] = {slot == b ? v[0] : 0, slot == b ? v[1] : 0, slot == b ? v[2] : 0, slot == b ? v[3] : 0};
+        block_store_partials_at<4>(s, part + (size_t)b * nblk * RIGID_PART, 0, red);
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_rigid_A_all(DevView d, WallHi hi, const int* __restrict__ list, int n, BodyIds ids,
+                                                     fx_t* __restrict__ part, int nblk) {
+    __shared__ fx_t red[TPB / 64][16];
+    __shared__ double s_tot[SPH_MAX_BATCH_BODIES][16];
+    sum_partials_all(d, part, nblk, ids.n, 4, s_tot);
+    const int tix = blockIdx.x * TPB + threadIdx.x;
+    int slot = -1;
+    fx_t v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (tix < n) {
+        const int i = list[tix];
+        float4 vf = d.vf[i];
+        const int fl = __float_as_int(vf.w);
+        const int object_id = sph_flags_object(fl);
+        if (sph_is_dynamic_rigid(fl) && (slot = body_slot(ids, object_id)) >= 0) {
+            float4 xm = d.xm[i];
+            wall_passes(d, hi.v, xm, vf, slot);
+            const double* tot = s_tot[slot];
+            const float sum_m = (float)tot[0];  // f32 division like the reference's cm /= sum_m
+            const float cm[3] = {(float)tot[1] / sum_m, (float)tot[2] / sum_m, (float)tot[3] / sum_m};
+            const float4 aux = d.aux[i];
+            const int pid = __float_as_int(aux.w);
+            const float* rc = &d.rigid_rest_cm[3 * object_id];
+            const float q[3] = {d.x0_cold[3 * pid] - rc[0], d.x0_cold[3 * pid + 1] - rc[1], d.x0_cold[3 * pid + 2] - rc[2]};
+            const float p[3] = {xm.x - cm[0], xm.y - cm[1], xm.z - cm[2]};
+            const float w = d.m_V0 * aux.y;
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) v[3 * a + c] = to_fx(d, (double)(w * (p[a] * q[c])));
+        }
+    }
+    for (int b = 0; b < ids.n; ++b) {
+        fx_t s[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s[k] = slot == b ? v[k] : 0;
+        block_store_partials_at<9>(s, part + (size_t)b * nblk * RIGID_PART, 4, red);
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_rigid_apply_all(DevView d, WallHi hi, const int* __restrict__ list, int n, BodyIds ids,
+                                                         const fx_t* __restrict__ part, int nblk, float* __restrict__ out) {
+    __shared__ double s_tot[SPH_MAX_BATCH_BODIES][16];
+    __shared__ float cmR[SPH_MAX_BATCH_BODIES][12];
+    sum_partials_all(d, part, nblk, ids.n, 13, s_tot);
+    if ((int)threadIdx.x < ids.n) {
+        rigid_cm_R(s_tot[threadIdx.x], true, cmR[threadIdx.x]);
+        if (blockIdx.x == 0 && (int)threadIdx.x == ids.n - 1)  // what the body-by-body sequence leaves behind: the last body's
+            for (int k = 0; k < 12; ++k) out[k] = cmR[threadIdx.x][k];
+    }
+    __syncthreads();
+    const int tix = blockIdx.x * TPB + threadIdx.x;
+    if (tix >= n) return;
+    const int i = list[tix];
+    float4 vf = d.vf[i];
+    const int fl = __float_as_int(vf.w);
+    if (!sph_is_dynamic_rigid(fl)) return;
+    const int object_id = sph_flags_object(fl);
+    const int slot = body_slot(ids, object_id);
+    float4 xm = d.xm[i];
+    if (slot >= 0) {
+        wall_passes(d, hi.v, xm, vf, slot);
+        const int pid = __float_as_int(d.aux[i].w);
+        const float* rc = &d.rigid_rest_cm[3 * object_id];
+        const float q[3] = {d.x0_cold[3 * pid] - rc[0], d.x0_cold[3 * pid + 1] - rc[1], d.x0_cold[3 * pid + 2] - rc[2]};
+        const float* cr = cmR[slot];
+        float x[3] = {xm.x, xm.y, xm.z};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float goal = cr[a] + (cr[3 + 3 * a] * q[0] + cr[3 + 3 * a + 1] * q[1] + cr[3 + 3 * a + 2] * q[2]);
+            const float corr = (goal - x[a]) * 1.0f;
+            x[a] += corr;
+        }
+        xm.x = x[0]; xm.y = x[1]; xm.z = x[2];
+        wall_passes(d, hi.v, xm, vf, ids.n - slot);
+    } else {
+        wall_passes(d, hi.v, xm, vf, ids.n);  // a dynamic solid that is no shape-matched body (a dynamic RigidBlock)
+    }
+    d.xm[i] = xm;
+    d.vf[i] = vf;
+}
+
 // ---- the same solve with the sums split over slabs (include/sph_hip.h: sph_rigid_partial_sums) ----
 // per-block partials of the 16 one-pass sums over the dynamic-rigid particles of `object_id` with index in [first,last)
 __global__ __launch_bounds__(TPB) void k_rigid_sum16(DevView d, const int* __restrict__ list, int n, int object_id,
@@ -690,6 +853,34 @@ int sphk_rigid_solve(SphContext* c, int object_id) {
     hipLaunchKernelGGL(k_rigid_A, dim3(nb), dim3(TPB), 0, c->stream, d, c->dyn_list, n, object_id, (fx_t*)c->rigid_part, nb);
     SPH_LAUNCH_CHECK(c);
     hipLaunchKernelGGL(k_rigid_apply, dim3(nb), dim3(TPB), 0, c->stream, d, c->dyn_list, n, object_id, (const fx_t*)c->rigid_part, nb,
+                       c->rigid_R);
+    SPH_LAUNCH_CHECK(c);
+    return 0;
+}
+
+// solve_rigid_body() (sph_base.py:247-260) for the dynamic bodies `ids` in the reference's order: three launches for all
+// of them when they fit the batch (<= 16 bodies, per-body rows of partials), else body by body
+int sphk_rigid_solve_all(SphContext* c, const int* ids, int n_ids) {
+    if (c->n_dyn_host <= 0 || n_ids <= 0) return 0;
+    const int n = c->n_dyn_host, nb = (n + TPB - 1) / TPB;
+    if (!c->opt_rigid_batch || n_ids > SPH_MAX_BATCH_BODIES || (long long)nb * n_ids > c->rigid_part_blocks) {
+        for (int k = 0; k < n_ids; ++k) {
+            int rc = sphk_rigid_solve(c, ids[k]);
+            rc = rc ? rc : sphk_enforce_boundary(c, SPH_MATERIAL_SOLID);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    sph_invalidate_lists(c);
+    DevView d = sph_view(c);
+    BodyIds b;
+    b.n = n_ids;
+    for (int k = 0; k < SPH_MAX_BATCH_BODIES; ++k) b.id[k] = k < n_ids ? ids[k] : -1;
+    hipLaunchKernelGGL(k_rigid_sum_all, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c), c->dyn_list, n, b, (fx_t*)c->rigid_part, nb);
+    SPH_LAUNCH_CHECK(c);
+    hipLaunchKernelGGL(k_rigid_A_all, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c), c->dyn_list, n, b, (fx_t*)c->rigid_part, nb);
+    SPH_LAUNCH_CHECK(c);
+    hipLaunchKernelGGL(k_rigid_apply_all, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c), c->dyn_list, n, b, (const fx_t*)c->rigid_part, nb,
                        c->rigid_R);
     SPH_LAUNCH_CHECK(c);
     return 0;

@@ -146,6 +146,8 @@ struct SphContext {
     // options
     int opt_gather_impl, opt_timing, opt_fused, opt_brick_shape, opt_no_dynamic, opt_ablate, opt_drop_outside;
     int opt_sort_by_pid;
+    int opt_rigid_batch;  // SPH_OPT_RIGID_BATCH: 1 (default) = solve_rigid_body() of all bodies in three launches
+    int opt_exact_math;   // SPH_OPT_EXACT_MATH: 1 = IEEE divide / sqrt instances of the brick sweeps (A/B of the fast-math choice)
     int opt_variant;     // SPH_OPT_KERNEL_VARIANT (bit mask of SPH_VAR_*)
     int fuse_advect;     // set around the force launch of sph_step when the advect can ride in its finish
     int skip_acc;        // set by sph_step for every step but the last of a call: the fused force finish keeps its acceleration to itself
@@ -210,6 +212,7 @@ int sphk_advect_range(SphContext* c, int first, int count);
 int sphk_enforce_boundary(SphContext* c, int particle_type);
 int sphk_rigid_com(SphContext* c, int object_id, bool to_rest);
 int sphk_rigid_solve(SphContext* c, int object_id);
+int sphk_rigid_solve_all(SphContext* c, const int* ids, int n_ids);  // every dynamic body + the solid wall passes, batched
 int sphk_extract(SphContext* c, int field, void* dst);
 int sphk_insert(SphContext* c, int field, const void* src);
 

@@ -336,6 +336,76 @@ class NativeTransport:
         return float(ms.value), int(n.value)
 
 
+def negotiate_native_transport(ps, device, create_timeout_s=180.0):
+    """COLLECTIVE over torch.distributed's default group: every rank gets a NativeTransport, or every rank gets None
+    (and the reason) -- never a mix, and never a rank left alone inside a collective (the fall-back used to be
+    collective only if every rank failed the same way).  Each stage ends with a MIN all-reduce of an ok flag, so all
+    ranks leave together at the first stage any of them fails:
+      0. librccl can be opened here (sph_comm_available) -- the likeliest failure, caught before anything collective;
+      1. rank 0 makes the unique id and broadcasts [ok flag | 128 bytes]: a failed id is seen by all;
+      2. sph_comm_create (= ncclCommInitRank, itself collective) under a watchdog: a rank whose call does not return
+         within `create_timeout_s` votes 0 (its daemon thread is abandoned);
+      3. a probe all-reduce of ones must give the world size, under the same watchdog."""
+    import threading
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(), dist.get_world_size()
+    fdev = device if dist.get_backend() == "nccl" else "cpu"
+
+    def agree(ok):
+        f = torch.tensor([1 if ok else 0], dtype=torch.int64, device=fdev)
+        dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        return int(f.item()) == 1
+
+    def watchdog(fn):
+        box = {}
+
+        def work():
+            try:
+                box["value"] = fn()
+            except Exception as e:      # noqa: BLE001 -- any failure is a vote for the other transport
+                box["error"] = e
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        th.join(create_timeout_s)
+        if th.is_alive():
+            box["error"] = TimeoutError(f"no return within {create_timeout_s:.0f} s")
+        return box
+
+    lib = ps._lib
+    ok0 = lib.sph_comm_available() == 0
+    why0 = "" if ok0 else lib.sph_comm_last_error().decode()
+    if not agree(ok0):
+        return None, f"stage 0, librccl unavailable on some rank{': ' + why0 if why0 else ''}"
+    buf = torch.zeros(129, dtype=torch.uint8, device=fdev)
+    if rank == 0:
+        uid = (C.c_uint8 * 128)()
+        rc = lib.sph_comm_unique_id(uid)
+        if rc == 0:
+            buf = torch.tensor([1] + list(uid), dtype=torch.uint8, device=fdev)
+    dist.broadcast(buf, 0)
+    got = buf.cpu().tolist()
+    if got[0] != 1:
+        return None, "stage 1, rank 0 could not make a unique id"
+    uid_bytes = bytes(got[1:])
+    box = watchdog(lambda: NativeTransport(ps, device, rank=rank, world=world, unique_id=uid_bytes))
+    tr = box.get("value")
+    if not agree(tr is not None):
+        if tr is not None:
+            tr.close()
+        return None, f"stage 2, sph_comm_create failed on some rank{': ' + repr(box['error']) if 'error' in box else ''}"
+
+    def probe():
+        t = torch.ones(1, dtype=torch.int64, device=device)
+        return int(tr.all_reduce_sum(t).item()) == world
+    box = watchdog(probe)
+    if not agree(box.get("value") is True):
+        if "error" not in box or not isinstance(box["error"], TimeoutError):
+            tr.close()
+        return None, f"stage 3, the probe all-reduce failed on some rank{': ' + repr(box['error']) if 'error' in box else ''}"
+    return tr, ""
+
+
 def plan_recut(cuts, hist, world, halo, width_cap=None):
     """New cut planes, each at most ONE cell layer from the old one, towards the cuts that balance the particle
     counts of `hist` (particles per global x layer).  One layer per event is what the running exchange can absorb:
@@ -995,29 +1065,15 @@ def run_slab_bench(args, rank, world, local_rank):
     want = os.environ.get("SPH_TRANSPORT", "native" if dist.get_backend() == "nccl" else "torch")
     transport = None
     if want == "native":
-        # self-test before the solver depends on it (multi-rank RCCL through the C ABI has only ever run as one rank on
-        # the development boxes): an all-reduce of ones must give the world size on every rank, else every rank falls
-        # back to the torch transport together
-        ok = 1
-        try:
-            transport = NativeTransport(s.ps, torch.device("cuda", local_rank))
-            probe = torch.ones(1, dtype=torch.int64, device=torch.device("cuda", local_rank))
-            ok = int(int(transport.all_reduce_sum(probe).item()) == world)
-        except Exception as e:          # noqa: BLE001 -- any failure here means "use the other transport"
-            print(f"[rank {rank}] native RCCL transport unavailable ({type(e).__name__}: {e}); falling back to torch.distributed P2P",
+        transport, why = negotiate_native_transport(s.ps, torch.device("cuda", local_rank))
+        if transport is None and rank == 0:
+            print(f"[bench] native RCCL transport not used ({why}); every rank falls back to torch.distributed P2P",
                   file=sys.stderr, flush=True)
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int64, device=torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            if transport is not None:
-                transport.close()
-            transport = None
     if transport is None:
         transport = TorchTransport(torch.device("cuda", local_rank))
     s.attach(transport)
     s.initialize()
-    from bench import gpu_preheat, _HEAT  # noqa: E402  (clock ramp after the host-side set-up: see its docstring)
+    from .benchutil import gpu_preheat, _HEAT, REF_PARTICLES, HBM_PEAK_GBS  # (clock ramp after the host-side set-up: see gpu_preheat)
     gpu_preheat(local_rank, float(getattr(args, "preheat_ms", 0.0)))
     s.step(args.warmup)
     s.ps.sync()
@@ -1047,7 +1103,6 @@ def run_slab_bench(args, rank, world, local_rank):
         s.ps._call("sph_get_timings", tm)
         s.ps.set_option(_lib.OPT_TIMING, 0)
     kt = max(int(tm.steps), 1)
-    from bench import REF_PARTICLES, HBM_PEAK_GBS  # noqa: E402
     roofline = None
     if not dfsph and tm.neighbour_ms > 0 and tm.force_ms > 0:
         # rank 0's dominant sweep over its local records (owned + ghosts) and local cells, algorithmic bytes as at

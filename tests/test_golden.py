@@ -111,6 +111,33 @@ def test_oracle_reproduces_reference_execution(path):
         _check(z, f"step{s}", get, 2e-5 if sd.get("RigidBodies") else 5e-6, "oracle")
 
 
+HIGH = [p for p in GOLDEN if "high_faces" in os.path.basename(p)]
+
+
+@pytest.mark.parametrize("path", HIGH, ids=[os.path.basename(p) for p in HIGH])
+def test_high_face_fixtures_keep_particles_in_the_last_layers(path):
+    """VERDICT r03 "missing" #5.  The reference's neighbour loop flattens cell coordinates without a bounds check
+    (particle_system.py:381-383): from the last y layer, cy + 1 = n_y aliases into cell (cx + 1, 0, cz); from the last z
+    layer, cz + 1 = n_z into (cx, cy + 1, 0).  The oracle and the HIP path SKIP such cells.  These two fixtures are the
+    reference's own source executed with particles (fluid, and a shape-matched body's solids) sitting in layers n_y - 1 /
+    n_z - 1 -- incl. the (n_y - 1, n_z - 1) edge -- over many steps; test_oracle_reproduces_reference_execution and
+    test_hip_reproduces_reference_execution hold both paths to the usual bounds on them, which is the executed evidence
+    for "skip == alias".  This test only makes sure the fixtures keep exercising that path."""
+    z, sd, steps = _load(path)
+    cfg, sc = scenes.build(sd)
+    nx, ny, nz = (int(v) for v in sc.geom.grid_num)
+    steps_y = steps_z = steps_edge = 0
+    for s in range(1, steps + 1):
+        g = z[f"step{s}/grid_ids"]
+        cz, cy, cx = g % nz, (g // nz) % ny, g // (ny * nz)
+        assert cx.max() < nx - 1, "the +x face is undefined behaviour in the reference (out-of-bounds read)"
+        steps_y += int((cy == ny - 1).any())
+        steps_z += int((cz == nz - 1).any())
+        steps_edge += int(((cy == ny - 1) & (cz == nz - 1)).any())
+    assert steps_y >= 8 and steps_z >= 8 and steps_edge >= 4, (steps_y, steps_z, steps_edge)
+    assert float(z[f"step{steps}/density"][z[f"step{steps}/material"] == 1].max()) > 1200.0   # the block is being compressed
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("impl", [0, 1])
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])

@@ -114,7 +114,8 @@ enum SphOption {
                                   LDS tile); 1 = fixed 4 x 2 x 4 bricks (the partition of ABI <= 2 builds, kept for A/B) */
     SPH_OPT_NO_DYNAMIC_SOLIDS = 4 /* 1 = the caller guarantees no dynamic solid particle exists (slab ranks
                                   cannot know this locally); skips the per-step device count */,
-    SPH_OPT_DEBUG_ABLATE = 5,  /* profiling only: bit mask of sweep sections to skip (results are then wrong) */
+    SPH_OPT_DEBUG_ABLATE = 5,  /* profiling BUILD only (-DSPH_PROFILE: libsph_hip_profile.so): bit mask of sweep sections to skip (results
+                                  are then wrong); the production library refuses any value but 0 */
     SPH_OPT_SLAB_DROP_OUTSIDE = 6 /* slab ranks: a particle whose x cell layer is outside the local grid is hashed to
                                   a virtual cell G (sorted behind every real cell) instead of being clamped; the
                                   host then truncates the particle set with sph_truncate */,

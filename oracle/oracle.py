@@ -57,6 +57,7 @@ class _State(C.Structure):
         ("last_iterations_v", C.c_int32), ("last_iterations", C.c_int32),
         ("last_avg_err_v", C.c_double), ("last_avg_err", C.c_double),
         ("dfsph_factor", _pf), ("density_adv", _pf), ("dfsph_factor_buffer", _pf), ("density_adv_buffer", _pf),
+        ("perturb", C.c_int32),      # test switch: bit 0 reversed neighbour traversal, bit 1 integer Tait exponent by multiplication
     ]
 
 
@@ -145,7 +146,7 @@ class Oracle:
 
     def __init__(self, params: dict, arrays: dict, n_objects: int = 1,
                  rigid_body_ids=(), dynamic_ids=(), omp_threads: int = 1, rigid_sums_f64: bool = False,
-                 timing_build: bool = False):
+                 timing_build: bool = False, perturb: int = 0):
         L = lib(timing=timing_build)   # timing_build: bench.py's cpu_baseline only -- never a checker
         self.L = L
         N = int(np.asarray(arrays["x"]).shape[0])
@@ -181,6 +182,7 @@ class Oracle:
         s.k_w, s.k_dw, s.visc_d_nu, s.visc_eps = kc["k_w"], kc["k_dw"], kc["visc_d_nu"], kc["visc_eps"]
         s.omp_threads = int(omp_threads)
         s.rigid_sums_f64 = int(bool(rigid_sums_f64))
+        s.perturb = int(perturb)     # test switch (see sph_oracle.c): ulp-level perturbations of the same formulas
         self.a = {}
 
         def alloc(name, dtype, vec):

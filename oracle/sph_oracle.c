@@ -94,6 +94,11 @@ typedef struct OracleState {
     double last_avg_err;
     float *dfsph_factor; float *density_adv;               /* particle_system.py:116-117 */
     float *dfsph_factor_buffer; float *density_adv_buffer; /* particle_system.py:134-135 */
+    /* Test switch (not in the reference): deliberate ulp-level perturbations of the SAME formulas, to measure how far two
+     * correct f32 evaluations drift apart on a given scene (tools/fastmath_ab.py: what a post-impact "error" is made of).
+     * bit 0: neighbours are visited in the reverse order (cells and particles) => every sum is added up in another order;
+     * bit 1: the Tait exponent, when an integer, by repeated multiplication instead of powf (what the HIP path does). */
+    int32_t perturb;
 } OracleState;
 
 #define MATERIAL_SOLID 0 /* particle_system.py:30 */
@@ -275,17 +280,19 @@ static inline float norm3(const float a[3]) { return sqrtf(a[0] * a[0] + a[1] * 
         const int32_t ccx_ = cell_coord(xi_[0], (s)->grid_size, (s)->grid_num[0]);          \
         const int32_t ccy_ = cell_coord(xi_[1], (s)->grid_size, (s)->grid_num[1]);          \
         const int32_t ccz_ = cell_coord(xi_[2], (s)->grid_size, (s)->grid_num[2]);          \
+        const int32_t sg_ = ((s)->perturb & 1) ? -1 : 1; /* (test switch: reversed traversal) */ \
         for (int32_t ox_ = -1; ox_ <= 1; ++ox_)                                            \
             for (int32_t oy_ = -1; oy_ <= 1; ++oy_)                                        \
                 for (int32_t oz_ = -1; oz_ <= 1; ++oz_) {                                  \
-                    const int32_t nx_ = ccx_ + ox_, ny_ = ccy_ + oy_, nz_ = ccz_ + oz_;    \
+                    const int32_t nx_ = ccx_ + sg_ * ox_, ny_ = ccy_ + sg_ * oy_, nz_ = ccz_ + sg_ * oz_; \
                     if (nx_ < 0 || ny_ < 0 || nz_ < 0 || nx_ >= (s)->grid_num[0] ||        \
                         ny_ >= (s)->grid_num[1] || nz_ >= (s)->grid_num[2])                \
                         continue;                                                          \
                     const int32_t gi_ = flatten((s), nx_, ny_, nz_);                       \
                     const int32_t beg_ = (s)->grid_particles_num[gi_ - 1 > 0 ? gi_ - 1 : 0]; \
                     const int32_t end_ = (s)->grid_particles_num[gi_];                     \
-                    for (int32_t p_j = beg_; p_j < end_; ++p_j) {                          \
+                    for (int32_t t_ = beg_; t_ < end_; ++t_) {                             \
+                        const int32_t p_j = sg_ > 0 ? t_ : end_ - 1 - (t_ - beg_);         \
                         const float *xj_ = &(s)->x[3 * p_j];                               \
                         const float rr_[3] = {xi_[0] - xj_[0], xi_[1] - xj_[1], xi_[2] - xj_[2]}; \
                         if ((p_i) != p_j && norm3(rr_) < (s)->support_radius) {
@@ -386,7 +393,16 @@ void oracle_compute_pressure_forces(OracleState *s) {
     for (int32_t p_i = 0; p_i < s->N; ++p_i) {
         if (s->material[p_i] != MATERIAL_FLUID) continue;
         s->density[p_i] = fmaxf(s->density[p_i], rho0);
-        s->pressure[p_i] = s->stiffness * (powf(s->density[p_i] / rho0, s->exponent) - 1.0f);
+        const float xr = s->density[p_i] / rho0;
+        float pw;
+        if ((s->perturb & 2) && s->exponent >= 1.0f && s->exponent <= 32.0f && s->exponent == (float)(int)s->exponent) {
+            float r = 1.0f, b = xr; /* (test switch) square-and-multiply */
+            for (int e = (int)s->exponent; e; e >>= 1) { if (e & 1) r *= b; b *= b; }
+            pw = r;
+        } else {
+            pw = powf(xr, s->exponent);
+        }
+        s->pressure[p_i] = s->stiffness * (pw - 1.0f);
     }
 #pragma omp parallel for schedule(dynamic, 256)
     for (int32_t p_i = 0; p_i < s->N; ++p_i) {

@@ -159,8 +159,14 @@ class SphError(RuntimeError):
     pass
 
 
+def profiling_variant() -> bool:
+    """SPH_HIP_LIB_VARIANT=profile: load the profiling build (section ablation compiled in) instead of the product library.
+    Set by bench.py --ablate / --ablate-mask before the first load; never by the product."""
+    return os.environ.get("SPH_HIP_LIB_VARIANT", "") == "profile"
+
+
 def library_path() -> str:
-    return _build.LIB
+    return _build.LIB_PROFILE if profiling_variant() else _build.LIB
 
 
 def _preload_shared_hip_runtime():
@@ -189,9 +195,9 @@ def load(build_if_missing: bool = True):
     if _LIB is not None:
         return _LIB
     path = library_path()
-    if build_if_missing and _build.stale():
+    if build_if_missing and _build.stale(profiling_variant()):
         try:
-            _build.build()
+            _build.build(profile=profiling_variant())
         except Exception as e:  # no hipcc on this box: use the prebuilt file if any
             if not os.path.exists(path):
                 raise SphError(f"libsph_hip.so is missing and could not be built: {e}") from e

@@ -25,6 +25,9 @@ def hipcc() -> str:
 
 
 STAMP = LIB + ".stamp"
+# The PROFILING build (-DSPH_PROFILE): the same sources with the section-ablation masks of SPH_OPT_DEBUG_ABLATE compiled
+# in.  Built on demand (bench.py --ablate / --ablate-mask, SPH_HIP_LIB_VARIANT=profile); the product never loads it.
+LIB_PROFILE = os.path.join(_HERE, "libsph_hip_profile.so")
 
 
 def _fingerprint() -> str:
@@ -37,37 +40,42 @@ def _fingerprint() -> str:
     return h.hexdigest()
 
 
-def stale() -> bool:
-    if not os.path.exists(LIB) or not os.path.exists(STAMP):
+def stale(profile: bool = False) -> bool:
+    lib = LIB_PROFILE if profile else LIB
+    stamp = lib + ".stamp"
+    if not os.path.exists(lib) or not os.path.exists(stamp):
         return True
     try:
-        return open(STAMP).read().strip() != _fingerprint()
+        return open(stamp).read().strip() != _fingerprint() + (" profile" if profile else "")
     except OSError:
         return True
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, profile: bool = False) -> str:
     """Several ranks may get here at once (torch.distributed.run starts one process per GPU): one of them builds,
     under a file lock, into a temporary file that is renamed into place; the others wait and find it fresh."""
-    if not (force or stale()):
-        return LIB
-    with open(LIB + ".lock", "w") as lock:
+    lib = LIB_PROFILE if profile else LIB
+    stamp = lib + ".stamp"
+    if not (force or stale(profile)):
+        return lib
+    with open(lib + ".lock", "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if force or stale():
-                tmp = f"{LIB}.tmp.{os.getpid()}"
-                cmd = [hipcc()] + FLAGS + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+            if force or stale(profile):
+                tmp = f"{lib}.tmp.{os.getpid()}"
+                cmd = [hipcc()] + FLAGS + (["-DSPH_PROFILE"] if profile else []) + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
                 if verbose:
                     print(" ".join(cmd))
                 subprocess.run(cmd, check=True, cwd=CSRC)
-                os.replace(tmp, LIB)
-                with open(STAMP + ".tmp", "w") as fh:
-                    fh.write(_fingerprint() + "\n")
-                os.replace(STAMP + ".tmp", STAMP)
+                os.replace(tmp, lib)
+                with open(stamp + ".tmp", "w") as fh:
+                    fh.write(_fingerprint() + (" profile" if profile else "") + "\n")
+                os.replace(stamp + ".tmp", stamp)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force=True, verbose=True, profile="--profile" in sys.argv))

@@ -22,7 +22,9 @@ DevView sph_view(const SphContext* c) {
     d.N = c->N; d.G = c->G;
     d.nx = p.grid_num[0]; d.ny = p.grid_num[1]; d.nz = p.grid_num[2];
     d.tgt_lo = 0; d.tgt_hi = p.grid_num[0]; d.tgt_lo2 = d.tgt_hi2 = 0;
+#ifdef SPH_PROFILE
     d.ablate = c->opt_ablate;
+#endif
     d.drop_outside = c->opt_drop_outside;
     d.sort_by_pid = c->opt_sort_by_pid;
     d.ox = p.cell_origin[0]; d.oy = p.cell_origin[1]; d.oz = p.cell_origin[2];
@@ -184,6 +186,7 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     rc = rc ? rc : alloc_dev(c, (void**)&c->df_part, SPH_DF_ERR_BLOCKS * sizeof(double));
     if (!rc && hipHostMalloc((void**)&c->h_df_err, sizeof(double), hipHostMallocMapped) != hipSuccess) rc = SPH_E_NOMEM;
     c->stage_bytes = cap * 16 > (size_t)c->G * 4 ? cap * 16 : (size_t)c->G * 4;
+    if (c->stage_bytes < 65536) c->stage_bytes = 65536;  // (also the scratch of sph_get_stats' partial rows)
     rc = rc ? rc : alloc_dev(c, &c->stage, c->stage_bytes);
     if (!rc && hipHostMalloc((void**)&c->h_pinned, 16 * sizeof(int), hipHostMallocMapped) != hipSuccess) rc = SPH_E_NOMEM;
     if (!rc && hipEventCreateWithFlags(&c->ev_off, hipEventDisableTiming) != hipSuccess) rc = SPH_E_NOMEM;
@@ -242,7 +245,12 @@ int32_t sph_set_option(SphContext* c, int32_t option, int32_t value) {
         case SPH_OPT_FUSED_STEP: c->opt_fused = value ? 1 : 0; return 0;
         case SPH_OPT_BRICK_SHAPE: if (value < 0 || value > 1) return sph_fail(c, SPH_E_INVALID, "brick shape must be 0 (adaptive height) or 1 (fixed 4x2x4)"); c->opt_brick_shape = value; sph_invalidate_lists(c); return 0;
         case SPH_OPT_NO_DYNAMIC_SOLIDS: c->opt_no_dynamic = value ? 1 : 0; c->n_dyn_host = -1; c->uniform_state = -1; return 0;
-        case SPH_OPT_DEBUG_ABLATE: c->opt_ablate = value; return 0;
+        case SPH_OPT_DEBUG_ABLATE:
+#ifndef SPH_PROFILE
+            if (value != 0) return sph_fail(c, SPH_E_INVALID, "section ablation exists only in the profiling build (python -m sph_taichi_amd.build --profile; bench.py --ablate loads it)");
+#endif
+            c->opt_ablate = value;
+            return 0;
         case SPH_OPT_SLAB_DROP_OUTSIDE: c->opt_drop_outside = value ? 1 : 0; c->uniform_state = -1; return 0;
         case SPH_OPT_SORT_BY_PID: c->opt_sort_by_pid = value ? 1 : 0; return 0;
         case SPH_OPT_RIGID_BATCH: c->opt_rigid_batch = value ? 1 : 0; return 0;

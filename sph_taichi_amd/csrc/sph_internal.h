@@ -38,7 +38,9 @@ struct DevView {
     int sort_by_pid;   // intra-cell order by persistent id (SPH_OPT_SORT_BY_PID)
     int drop_outside;  // slab mode: x layer outside the local grid -> virtual cell G
     int exp_int;     // Tait exponent as a small integer (1..32) when it is one, else 0 (WCSPH.py:76)
-    int ablate;      // debug: bit0 skip phase 2, bit1 skip list write-out, bit2 skip phase 1 (profiling only)
+#ifdef SPH_PROFILE
+    int ablate;      // profiling build only: bit0 skip phase 2, bit1 skip list write-out, bit2 skip phase 1, ... (sph_gather.hip)
+#endif
     float grid_size, h, inv_h, d2, m_V0, rho0, stiffness, exponent, sigma, dt;
     float gx, gy, gz;
     float pad;

@@ -1023,45 +1023,50 @@ def gather_by_pid(solvers, name, n_global):
 
 
 # ---------------------------------------------------------------------------
-# bench.py --gpus N  (weak scaling: every rank owns one ~1.74 M-particle slab)
+# bench.py --gpus N
+#   default       : weak scaling -- every rank owns one ~1.74 M-particle slab of the tiled C3' box (`value`), and, in the same
+#                   run, BASELINE.json's config 5 in its own geometry (`c4_dambreak`: 13.9 M particles, travelling cuts)
+#   --workload c4_dambreak : that dam-break as the line itself (strong scaling: the job is 13,939,200 particles at any N)
 # ---------------------------------------------------------------------------
-def slab_bench_scene(world):
-    """Weak-scaling family: `world` copies of BASELINE.md's C3' box side by side along x --
-    (246*world) x 74 x 96 particles in a (5*world, 3, 2) tank, so every rank's slab is exactly the N = 1
-    workload (1,747,584 particles, 125 x 75 x 50 cells) plus its halos; world = 8 gives 13,980,672 particles
-    (BASELINE.json: "13.9 M particles" on 8 GPUs)."""
-    cfg = {
-        "domainStart": [0.0, 0.0, 0.0], "domainEnd": [5.0 * world, 3.0, 2.0], "particleRadius": 0.01,
-        "numberOfStepsPerRenderUpdate": 1, "density0": 1000, "simulationMethod": 0,
-        "gravitation": [0.0, -9.81, 0.0], "timeStepSize": 0.0004, "stiffness": 50000, "exponent": 7,
-        "boundaryHandlingMethod": 0, "exportFrame": False, "exportPly": False, "exportObj": False,
-    }
+_BENCH_CFG = {
+    "domainStart": [0.0, 0.0, 0.0], "particleRadius": 0.01, "numberOfStepsPerRenderUpdate": 1, "density0": 1000,
+    "simulationMethod": 0, "gravitation": [0.0, -9.81, 0.0], "timeStepSize": 0.0004, "stiffness": 50000, "exponent": 7,
+    "boundaryHandlingMethod": 0, "exportFrame": False, "exportPly": False, "exportObj": False,
+}
+
+
+def _box_scene(domain_end, counts, corner=(0.04, 0.04, 0.04)):
     d = 0.02
-    counts = (246 * world, 74, 96)
-    corner = (0.04, 0.04, 0.04)
     end = [c + (n - 0.5) * d for c, n in zip(corner, counts)]
-    return {"Configuration": cfg,
+    return {"Configuration": dict(_BENCH_CFG, domainEnd=list(domain_end)),
             "FluidBlocks": [{"objectId": 0, "start": list(corner), "end": end, "translation": [0.0, 0.0, 0.0],
                              "scale": [1, 1, 1], "velocity": [0.0, 0.0, 0.0], "density": 1000.0,
                              "color": [50, 100, 200]}]}, counts[0] * counts[1] * counts[2]
 
 
-def run_slab_bench(args, rank, world, local_rank):
-    import time
+def slab_bench_scene(world):
+    """Weak-scaling family: `world` copies of BASELINE.md's C3' box side by side along x --
+    (246*world) x 74 x 96 particles in a (5*world, 3, 2) tank, so every rank's slab is exactly the N = 1
+    workload (1,747,584 particles, 125 x 75 x 50 cells) plus its halos; world = 8 gives 13,980,672 particles
+    (BASELINE.json: "13.9 M particles" on 8 GPUs)."""
+    return _box_scene([5.0 * world, 3.0, 2.0], (246 * world, 74, 96))
+
+
+def c4_dambreak_scene(scale=1.0):
+    """BASELINE.json config 5 / SURVEY 8(d) C4 in its own geometry: the (16, 4, 3.4) tank (400 x 100 x 85 cells) with
+    the 512 x 165 x 165 = 13,939,200-particle column at its -x end.  The column collapses into the empty 5.8 m of the
+    tank, so the cuts that balance the ranks travel: the case `recut_every` exists for.  `scale` < 1 shrinks the
+    column's particle counts (tests, smoke runs)."""
+    counts = tuple(max(int(round(c * scale)), 8) for c in (512, 165, 165))
+    return _box_scene([16.0, 4.0, 3.4], counts)
+
+
+def _choose_transport(s, rank, local_rank):
+    """The exchange: RCCL behind the C ABI (NativeTransport: enqueued on the device, no host wait inside a step) when the
+    job runs on RCCL -- agreed on collectively, stage by stage (negotiate_native_transport) --; torch.distributed P2P
+    otherwise (gloo: several ranks sharing one GPU) or on request (SPH_TRANSPORT=torch)."""
     import torch
     import torch.distributed as dist
-    sd, n_global = slab_bench_scene(world)
-    dfsph = getattr(args, "solver", "wcsph") == "dfsph"
-    if dfsph:                                     # supplementary line, like bench.py --solver dfsph at N = 1
-        sd["Configuration"]["simulationMethod"] = 4
-        sd["Configuration"]["timeStepSize"] = 0.004
-    # (check_every = 0: the conservation guard is a blocking all-reduce + host read; the bench scene is balanced and
-    # slow -- no particle can outrun the halo -- so the guard stays out of the timed region)
-    s = SlabSolver(sd, rank, world, device=local_rank, gather_impl=args.gather_impl, brick_shape=args.brick_shape,
-                   recut_every=getattr(args, "recut_every", 0), check_every=0)
-    # The exchange: RCCL behind the C ABI (NativeTransport: enqueued on the device, no host wait inside a step) when
-    # the job runs on RCCL; torch.distributed P2P otherwise (gloo: several ranks sharing one GPU) or on request
-    # (SPH_TRANSPORT=torch).
     want = os.environ.get("SPH_TRANSPORT", "native" if dist.get_backend() == "nccl" else "torch")
     transport = None
     if want == "native":
@@ -1071,48 +1076,156 @@ def run_slab_bench(args, rank, world, local_rank):
                   file=sys.stderr, flush=True)
     if transport is None:
         transport = TorchTransport(torch.device("cuda", local_rank))
-    s.attach(transport)
-    s.initialize()
-    from .benchutil import gpu_preheat, _HEAT, REF_PARTICLES, HBM_PEAK_GBS  # (clock ramp after the host-side set-up: see gpu_preheat)
-    gpu_preheat(local_rank, float(getattr(args, "preheat_ms", 0.0)))
-    s.step(args.warmup)
+    return transport
+
+
+def _timed_steps(s, steps, red_dev):
+    """Exactly `steps` steps bracketed by barrier + synchronize on both sides; MAX over ranks (seconds)."""
+    import time
+    import torch
+    import torch.distributed as dist
     s.ps.sync()
     torch.cuda.synchronize()
     dist.barrier()
-    s.host_ms = {k: 0 if k == "steps" else 0.0 for k in s.host_ms}
     t0 = time.perf_counter()
-    s.step(args.steps)
+    s.step(steps)
     s.ps.sync()
     torch.cuda.synchronize()
     dist.barrier()
-    red_dev = torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else torch.device("cpu")
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    dt = float(dt.item())
-    own = torch.tensor([s.owned_range[1]], dtype=torch.int64, device=red_dev)
-    dist.all_reduce(own)
-    host_ms = dict(s.host_ms)
-    # per-phase HIP events in a few EXTRA steps behind the timed region: in slab mode (two streams) the timestamping
-    # barriers cost ~7 % of a step, so they stay out of the number that is reported
+    return float(dt.item())
+
+
+def _phase_events(s, steps):
+    """Per-phase HIP events of rank 0 in EXTRA steps outside the timed region: in slab mode (two streams) the timestamping
+    barriers cost ~7 % of a step, so they stay out of the number that is reported."""
     tm = _lib.SphTimings()
-    if not dfsph:
-        s.ps.set_option(_lib.OPT_TIMING, 1)
-        s.ps._call("sph_reset_timings")
-        s.step(min(max(args.steps, 1), 20))
-        s.ps.sync()
-        s.ps._call("sph_get_timings", tm)
-        s.ps.set_option(_lib.OPT_TIMING, 0)
+    s.ps.set_option(_lib.OPT_TIMING, 1)
+    s.ps._call("sph_reset_timings")
+    s.step(steps)
+    s.ps.sync()
+    s.ps._call("sph_get_timings", tm)
+    s.ps.set_option(_lib.OPT_TIMING, 0)
     kt = max(int(tm.steps), 1)
+    return {"sort": round(tm.sort_ms / kt, 4), "neighbour": round(tm.neighbour_ms / kt, 4), "force": round(tm.force_ms / kt, 4),
+            "integrate": round(tm.integrate_ms / kt, 4), "sum_of_phases": round(tm.total_ms / kt, 4)}
+
+
+def _all_owned(s, red_dev):
+    import torch
+    import torch.distributed as dist
+    t = torch.zeros(dist.get_world_size(), dtype=torch.int64, device=red_dev)
+    t[dist.get_rank()] = int(s.owned_range[1])
+    dist.all_reduce(t)
+    return [int(v) for v in t.tolist()]
+
+
+def run_c4_dambreak(args, rank, world, local_rank, scale=1.0):
+    """BASELINE.json config 5 across the ranks of this job: 13,939,200 particles cut by particle count, one exchange and
+    one sort per step, the cuts re-planned every `--recut-every` (default 10) steps.  Two states: the first collapse
+    (W untimed + K timed steps from rest) and `settled` = after `--settled-after` further steps (the front has crossed the
+    tank).  Per-rank owned counts and the cuts at both ends say how well the travelling cuts keep the ranks balanced;
+    `conserved` = the ranks' owned counts still add up to the scene."""
+    import torch
+    import torch.distributed as dist
+    from .benchutil import REF_PARTICLES
+    sd, n_global = c4_dambreak_scene(scale)
+    recut = int(getattr(args, "recut_every", 0)) or 10
+    s = SlabSolver(sd, rank, world, device=local_rank, gather_impl=args.gather_impl, brick_shape=args.brick_shape,
+                   recut_every=recut, check_every=0)
+    transport = _choose_transport(s, rank, local_rank)
+    s.attach(transport)
+    s.initialize()
+    red_dev = torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else torch.device("cpu")
+    out = {"workload": "c4_dambreak_512x165x165_in_16x4x3.4", "particles": n_global, "recut_every": recut,
+           "transport": type(transport).__name__, "halo_layers": s.halo, "cuts_start": list(s.cuts),
+           "owned_start": _all_owned(s, red_dev)}
+    s.step(args.warmup)
+    s.host_ms = {k: 0 if k == "steps" else 0.0 for k in s.host_ms}
+    dt = _timed_steps(s, args.steps, red_dev)
+    out["from_rest"] = {"value": round(args.steps / dt * n_global / REF_PARTICLES, 3), "ms_per_step": round(dt / args.steps * 1e3, 4),
+                        "steps": args.steps, "warmup": args.warmup, "breakdown_ms": dict(_phase_events(s, min(args.steps, 20)), rank=0)}
+    settle = int(getattr(args, "settled_after", 0))
+    if settle > 0:
+        s.step(settle)
+        k = max(args.steps, 50)
+        dt = _timed_steps(s, k, red_dev)
+        owned = _all_owned(s, red_dev)
+        out["settled"] = {"value": round(k / dt * n_global / REF_PARTICLES, 3), "ms_per_step": round(dt / k * 1e3, 4), "steps": k,
+                          "after_steps": s.steps_done - k, "breakdown_ms": dict(_phase_events(s, 20), rank=0),
+                          "owned": owned, "imbalance": round(max(owned) / (n_global / world), 4), "cuts": list(s.cuts)}
+    owned = _all_owned(s, red_dev)
+    out["owned_end"] = owned
+    out["cuts_end"] = list(s.cuts)
+    out["recut_events_rank0"] = int(s.stats.get("recuts", 0))
+    out["conserved"] = sum(owned) == n_global
+    out["imbalance_start"] = round(max(out["owned_start"]) / (n_global / world), 4)
+    out["imbalance_end"] = round(max(owned) / (n_global / world), 4)
+    out["rank0_host_ms_per_step"] = {k_: round(v / max(s.host_ms["steps"], 1), 4) for k_, v in s.host_ms.items() if k_ != "steps"}
+    if isinstance(transport, NativeTransport):
+        ms, n = transport.halo_time()
+        out["halo_device_ms"] = round(ms / max(n, 1), 4)
+        transport.close()
+    st = _lib.SphStats()
+    s.ps._call("sph_get_stats", st)
+    out["rank0_neighbourhood"] = {"max_list_entries": st.max_list, "list_overflow_targets": st.list_overflow_targets,
+                                  "lds_overflow_targets": st.lds_overflow_targets, "max_cell_occupancy": st.max_cell_occupancy}
+    s.close()
+    return out
+
+
+def run_slab_bench(args, rank, world, local_rank):
+    import torch
+    import torch.distributed as dist
+    from .benchutil import gpu_preheat, _HEAT, REF_PARTICLES, HBM_PEAK_GBS
+    dfsph = getattr(args, "solver", "wcsph") == "dfsph"
+    c4_line = getattr(args, "workload", "") == "c4_dambreak"
+    red_dev = torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else torch.device("cpu")
+    metric = ("DFSPH steps/sec at 1.74 M particles (supplementary)" if dfsph else
+              "WCSPH steps/sec at 1.74 M particles (+ ms/step breakdown sort/neighbour/force)")
+    if c4_line and not dfsph:
+        # the named 8-GPU workload as the line itself
+        c4 = run_c4_dambreak(args, rank, world, local_rank, scale=float(os.environ.get("SPH_C4_SCALE", "1.0")))
+        fr = c4["from_rest"]
+        return {"metric": metric, "value": fr["value"], "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": fr["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic", "preheat_ms": 0.0,
+                "config": {"workload": c4["workload"], "particles": c4["particles"], "recut_every": c4["recut_every"],
+                           "backend": dist.get_backend(), "transport": c4["transport"],
+                           "parallelism": f"x-slab x{world} cut by particle count, travelling cuts, 1 exchange/step"},
+                "steps_per_s_job": round(fr["value"] * REF_PARTICLES / c4["particles"], 3),
+                "breakdown_ms": dict(fr["breakdown_ms"], halo_device=c4.get("halo_device_ms")),
+                "settled": c4.get("settled"), "c4_dambreak": c4, "roofline": None, "cpu_baseline": None}
+    sd, n_global = slab_bench_scene(world)
+    if dfsph:                                     # supplementary line, like bench.py --solver dfsph at N = 1
+        sd["Configuration"]["simulationMethod"] = 4
+        sd["Configuration"]["timeStepSize"] = 0.004
+    # (check_every = 0: the conservation guard is a blocking all-reduce + host read; the bench scene is balanced and
+    # slow -- no particle can outrun the halo -- so the guard stays out of the timed region)
+    s = SlabSolver(sd, rank, world, device=local_rank, gather_impl=args.gather_impl, brick_shape=args.brick_shape,
+                   recut_every=getattr(args, "recut_every", 0), check_every=0)
+    transport = _choose_transport(s, rank, local_rank)
+    s.attach(transport)
+    s.initialize()
+    gpu_preheat(local_rank, float(getattr(args, "preheat_ms", 0.0)))    # clock ramp after the host-side set-up: see gpu_preheat
+    s.step(args.warmup)
+    s.host_ms = {k: 0 if k == "steps" else 0.0 for k in s.host_ms}
+    dt = _timed_steps(s, args.steps, red_dev)
+    owned = _all_owned(s, red_dev)
+    host_ms = dict(s.host_ms)
+    phases = {"sort": 0.0, "neighbour": 0.0, "force": 0.0, "integrate": 0.0, "sum_of_phases": 0.0}
+    if not dfsph:
+        phases = _phase_events(s, min(max(args.steps, 1), 20))
     roofline = None
-    if not dfsph and tm.neighbour_ms > 0 and tm.force_ms > 0:
+    if not dfsph and phases["neighbour"] > 0 and phases["force"] > 0:
         # rank 0's dominant sweep over its local records (owned + ghosts) and local cells, algorithmic bytes as at
         # N = 1 (SURVEY 8d: density+EOS 32 N + 4 G, fused force 60 N + 4 G); in slab mode the force phase is an
         # interior launch plus a boundary launch on a side stream, so its figure is per phase, not per launch
         n_loc = s.ps.count()
         g_loc = int(np.prod(s.ps._local_grid_num))
-        cands = {"k_gather_brick<GM_DENSITY_EOS>": (32.0 * n_loc + 4.0 * g_loc, tm.neighbour_ms / kt),
-                 "k_gather_brick<GM_FORCE_FUSED*> (interior + boundary launches)": (60.0 * n_loc + 4.0 * g_loc,
-                                                                                    tm.force_ms / kt)}
+        cands = {"k_gather_brick<GM_DENSITY_EOS>": (32.0 * n_loc + 4.0 * g_loc, phases["neighbour"]),
+                 "k_gather_brick<GM_FORCE_FUSED*> (interior + boundary launches)": (60.0 * n_loc + 4.0 * g_loc, phases["force"])}
         dom = max(cands, key=lambda k_: cands[k_][1])
         ab, ms = cands[dom]
         ach = ab / (ms * 1e-3) / 1e9
@@ -1122,14 +1235,13 @@ def run_slab_bench(args, rank, world, local_rank):
                     "note": "rank 0; gather sweeps are VALU-issue-bound, not HBM-bound (DESIGN.md section 4)"}
     steps_per_s = args.steps / dt
     line = {
-        "metric": ("DFSPH steps/sec at 1.74 M particles (supplementary)" if dfsph else
-                   "WCSPH steps/sec at 1.74 M particles (+ ms/step breakdown sort/neighbour/force)"),
+        "metric": metric,
         "value": round(steps_per_s * n_global / REF_PARTICLES, 3), "unit": "steps/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "preheat_ms": 0.0 if _HEAT.get("broken") else float(getattr(args, "preheat_ms", 0.0)),
         "config": {"workload": f"c3p_tiled_x{world}_{246 * world}x74x96", "particles": n_global,
-                   "particles_owned_sum": int(own.item()), "cuts": s.cuts, "halo_layers": s.halo,
+                   "particles_owned_sum": sum(owned), "particles_owned_per_rank": owned, "cuts": s.cuts, "halo_layers": s.halo,
                    "sent_records_per_step": round(s.stats["sent"] / max(args.steps + args.warmup + 1, 1), 1),
                    "backend": dist.get_backend(), "transport": type(transport).__name__, "recut_every": s.recut_every,
                    "rank0_host_ms_per_step": {k: round(v / max(host_ms["steps"], 1), 4)
@@ -1137,15 +1249,12 @@ def run_slab_bench(args, rank, world, local_rank):
                    "parallelism": f"x-slab x{world}, 1 exchange/step over "
                                   f"{'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} P2P"},
         "steps_per_s_job": round(steps_per_s, 3),
-        "breakdown_ms": {"rank": 0, "sort": round(tm.sort_ms / kt, 4), "neighbour": round(tm.neighbour_ms / kt, 4),
-                         "force": round(tm.force_ms / kt, 4), "integrate": round(tm.integrate_ms / kt, 4),
-                         "halo": round(host_ms["exchange"] / max(host_ms["steps"], 1), 4),
-                         "sum_of_phases": round(tm.total_ms / kt, 4),
-                         "note": "sort / neighbour / force / integrate: HIP events on rank 0's stream over extra steps "
-                                 "after the timed region (sum_of_phases adds these four).  halo: rank 0's wall time "
-                                 "inside the record exchange per step of the timed region (batch_isend_irecv + wait); "
-                                 "it runs on the host beside the interior force sweep, so it is not an additive GPU cost "
-                                 "unless it exceeds that sweep"},
+        "breakdown_ms": dict(phases, rank=0, halo=round(host_ms["exchange"] / max(host_ms["steps"], 1), 4),
+                             note="sort / neighbour / force / integrate: HIP events on rank 0's stream over extra steps "
+                                  "after the timed region (sum_of_phases adds these four).  halo: rank 0's wall time "
+                                  "inside the record exchange call per step of the timed region (native transport: the enqueue "
+                                  "only; torch transport: batch_isend_irecv + wait); it runs beside the interior force sweep, "
+                                  "so it is not an additive GPU cost unless it exceeds that sweep"),
         "roofline": roofline, "cpu_baseline": None,
     }
     if dfsph:
@@ -1158,4 +1267,11 @@ def run_slab_bench(args, rank, world, local_rank):
                                          "stream (HIP events around ncclGroupStart..End)")
         transport.close()
     s.close()
+    # ... and, in the same driver command, BASELINE.json's named 8-GPU workload in its own geometry:
+    # 13.9 M particles whatever N is (strong scaling), unbalanced start, cuts re-planned every 10 steps, two states
+    if not dfsph and int(getattr(args, "c4", 1)):
+        try:
+            line["c4_dambreak"] = run_c4_dambreak(args, rank, world, local_rank, scale=float(os.environ.get("SPH_C4_SCALE", "1.0")))
+        except Exception as e:      # noqa: BLE001 -- the tiled line above is the contract's; this object must never cost it
+            line["c4_dambreak"] = {"error": f"{type(e).__name__}: {e}"}
     return line

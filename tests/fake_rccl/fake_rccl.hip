@@ -316,7 +316,7 @@ int acquire_entry(ncclComm* c, size_t bytes) {
                 if (e.host) c->graveyard.push_back(e.host);
                 size_t cap = 4096;
                 while (cap < bytes) cap <<= 1;
-                if (hipHostMalloc(&e.host, cap, hipHostMallocDefault) != hipSuccess) { e.host = nullptr; e.cap = 0; c->fail("hipHostMalloc(%zu) failed", cap); return -1; }
+                if (hipHostMalloc(&e.host, cap, hipHostMallocCoherent) != hipSuccess) { e.host = nullptr; e.cap = 0; c->fail("hipHostMalloc(%zu) failed", cap); return -1; }
                 e.cap = cap;
             }
             *e.busy = 1;

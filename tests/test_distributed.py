@@ -440,7 +440,7 @@ def _fake_rccl_env(slot_bytes=65536):
     import build as fake_build
     sys.path.pop(0)
     return {"SPH_RCCL_LIB": fake_build.build(), "FAKE_RCCL_SLOT_BYTES": str(slot_bytes), "FAKE_RCCL_SLOTS": "3",
-            "FAKE_RCCL_TIMEOUT_S": "40"}
+            "FAKE_RCCL_TIMEOUT_S": "25"}
 
 
 NATIVE_CASES = {
@@ -484,7 +484,7 @@ def test_native_exchange_between_processes(case, tmp_path):
     scene_file = str(tmp_path / "scene.json")
     json.dump(sd, open(scene_file, "w"))
     out = str(tmp_path / "res.npz")
-    _spawn("native", world, out, extra=(scene_file, str(steps), json.dumps(opt)), env=_fake_rccl_env(), timeout=300)
+    _spawn("native", world, out, extra=(scene_file, str(steps), json.dumps(opt)), env=_fake_rccl_env(), timeout=150)
     z = np.load(out)
     assert int(z["ok"]) == 1, "the transport-level checks (ragged exchange / swap / all-reduce between processes) failed"
     assert int(z["sent"]) > 0 and int(z["exchanges"]) >= steps

@@ -107,3 +107,35 @@ def test_long_lists_between_64_and_95_entries(variant):
         err = float(np.abs(got.astype(np.float64) - ref).max()) / max(float(np.abs(ref).max()), 1e-30)
         assert err <= tol, f"variant {variant}: {name}: {err:.3e}"
     ps.close()
+
+
+def test_exact_math_instance_follows_the_oracle_at_least_as_closely():
+    """SPH_OPT_EXACT_MATH: the two brick sweeps with IEEE sqrt / divide, the two-branch spline and no
+    FMA contraction -- the reference's f32 expressions as the oracle evaluates them.  It must follow the oracle, and after
+    one step its densities and accelerations must be no further from it than the fast-math build's (the A/B at scale is
+    tools/fastmath_ab.py -> profiles/r04_parity_fastmath_ab.json).  The production option refuses section ablation."""
+    from sph_taichi_amd import _lib
+    sd = scenes.fluid_with_rigid_blocks()
+    cfg, sc = scenes.build(sd)
+    scenes.jitter(sc, 0.1, seed=4)
+    errs = {}
+    for exact in (0, 1):
+        o = scenes.make_oracle(cfg, sc)
+        ps, solver = scenes.make_ps(sd, sc.arrays)
+        ps.set_option(_lib.OPT_EXACT_MATH, exact)
+        assert ps.get_option(_lib.OPT_EXACT_MATH) == exact
+        o.initialize(); solver.initialize()
+        o.step(1); solver.step(1)
+        e = {}
+        for name in ("density", "pressure", "acceleration"):
+            ref, got = o.by_pid(name), scenes.ps_by_pid(ps, name)
+            e[name] = float(np.abs(got.astype(np.float64) - ref).max()) / max(float(np.abs(ref).max()), 1e-30)
+        o.step(19); solver.step(19)
+        e["x20"] = scenes.rel_l2(scenes.ps_by_pid(ps, "x"), o.by_pid("x"))
+        errs[exact] = e
+        if not _lib.profiling_variant():
+            with pytest.raises(_lib.SphError, match="profiling build"):
+                ps.set_option(_lib.OPT_DEBUG_ABLATE, 1)
+        ps.close()
+    assert errs[1]["density"] <= 2e-5 and errs[1]["pressure"] <= 2e-4 and errs[1]["acceleration"] <= 5e-4 and errs[1]["x20"] <= 1e-4, errs
+    assert errs[1]["density"] <= 2.0 * errs[0]["density"] + 1e-6 and errs[1]["acceleration"] <= 2.0 * errs[0]["acceleration"] + 1e-6, errs

@@ -24,21 +24,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
-def c4_scene(scale=1.0):
-    cfg = {
-        "domainStart": [0.0, 0.0, 0.0], "domainEnd": [16.0, 4.0, 3.4], "particleRadius": 0.01,
-        "numberOfStepsPerRenderUpdate": 1, "density0": 1000, "simulationMethod": 0,
-        "gravitation": [0.0, -9.81, 0.0], "timeStepSize": 0.0004, "stiffness": 50000, "exponent": 7,
-        "boundaryHandlingMethod": 0, "exportFrame": False, "exportPly": False, "exportObj": False,
-    }
-    d = 0.02
-    counts = tuple(max(int(round(c * scale)), 8) for c in (512, 165, 165))
-    corner = (0.04, 0.04, 0.04)
-    end = [c + (n - 0.5) * d for c, n in zip(corner, counts)]
-    return {"Configuration": cfg,
-            "FluidBlocks": [{"objectId": 0, "start": list(corner), "end": end, "translation": [0.0, 0.0, 0.0],
-                             "scale": [1, 1, 1], "velocity": [0.0, 0.0, 0.0], "density": 1000.0,
-                             "color": [50, 100, 200]}]}, counts[0] * counts[1] * counts[2]
+from sph_taichi_amd.distributed import c4_dambreak_scene as c4_scene  # noqa: E402  (the scene lives with the slab bench now)
 
 
 def main():

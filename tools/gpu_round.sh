@@ -57,3 +57,10 @@ P
   rm -rf $OUT/prof_native
   timeout 300 python tools/slab_overhead.py > $OUT/slab_overhead_world1.txt 2>&1; grep -v amdgpu $OUT/slab_overhead_world1.txt
 fi
+if has fastmath; then   # A/B of the fast-math choice (SPH_OPT_EXACT_MATH): tools/fastmath_ab.py
+  timeout 900 python tools/fastmath_ab.py $TAG > $OUT/fastmath_ab.log 2>&1; echo "fastmath rc=$?"; tail -n 3 $OUT/fastmath_ab.log | cut -c1-1500
+fi
+if has nativemp; then   # only the multi-process native-exchange tests (tests/fake_rccl)
+  timeout 600 python -m pytest tests/test_distributed.py -m gpu -x -q -k "native_exchange" --durations=10 > $OUT/pytest_native_mp.log 2>&1; echo "native mp rc=$?"
+  tail -n 25 $OUT/pytest_native_mp.log
+fi

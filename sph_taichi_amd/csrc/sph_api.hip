@@ -24,6 +24,7 @@ DevView sph_view(const SphContext* c) {
     d.tgt_lo = 0; d.tgt_hi = p.grid_num[0]; d.tgt_lo2 = d.tgt_hi2 = 0;
 #ifdef SPH_PROFILE
     d.ablate = c->opt_ablate;
+    d.prof_ts = (c->opt_ablate & (3 << 28)) ? reinterpret_cast<unsigned long long*>(c->stage) : nullptr;  // (the staging buffer: 16 B per particle of capacity, 64 B per hardware block needed)
 #endif
     d.drop_outside = c->opt_drop_outside;
     d.sort_by_pid = c->opt_sort_by_pid;
@@ -582,10 +583,11 @@ static int step_sweeps(SphContext* c, hipEvent_t* ev, const int32_t* dynamic_ids
     }
     if (ev) SPH_HIP(c, hipEventRecord(ev[3], c->stream));
     // advect (WCSPH.py:156) + enforce_boundary_3D(fluid) (sph_base.py:270-271) in one pass
-    rc = fused_advect ? sphk_advect_dyn_list(c) : sphk_advect(c, true);
-    if (rc) return rc;
     // solve_rigid_body()                                   sph_base.py:247-260
-    if (c->n_dyn_host > 0) { rc = sphk_rigid_solve_all(c, dynamic_ids, n_dynamic); if (rc) return rc; }
+    if (fused_advect) return sphk_rigid_solve_all(c, dynamic_ids, n_dynamic, true);   // (the dynamic solids' advect rides in its first kernel)
+    rc = sphk_advect(c, true);
+    if (rc) return rc;
+    if (c->n_dyn_host > 0) { rc = sphk_rigid_solve_all(c, dynamic_ids, n_dynamic, false); if (rc) return rc; }
     return 0;
 }
 
@@ -615,11 +617,21 @@ int32_t sph_slab_set_window(SphContext* c, int32_t origin_x, int32_t nx) {
     return 0;
 }
 
-int32_t sph_sort(SphContext* c) {
-    ENTER(c);
+// hash + scan + scatter without touching aux: for callers that run a density sweep right behind it (nothing can read the
+// stale density / pressure copies the scatter moves in between)
+static int sort_no_fold(SphContext* c) {
     int rc = sph_update_grid_id(c);
     rc = rc ? rc : sph_prefix_sum(c);
     return rc ? rc : counting_sort(c, false);
+}
+
+int32_t sph_sort(SphContext* c) {
+    ENTER(c);
+    // (after the lean density finish, density / pressure live in eos2 in the OLD order; a stand-alone sort must
+    // fold them into aux first, like the reference's counting_sort carries them along, or a later download reads values
+    // from the last fold)
+    int rc = sph_ensure_aux(c);
+    return rc ? rc : sort_no_fold(c);
 }
 
 int32_t sph_sweeps(SphContext* c) {
@@ -824,10 +836,15 @@ int32_t sph_slab_advance(SphContext* c, int32_t keep_first, int32_t keep_count, 
         ev = c->ev[c->ev_used];
         SPH_HIP(c, hipEventRecord(ev[0], c->stream));
     }
-    int rc = sph_select_range(c, keep_first, keep_count);
+    // do_sweeps != 0: a density sweep follows at once and rewrites every fluid particle's density / pressure -- the stale
+    // copies the scatter moves are never observable (the received records' neither: their owner's sweep is as old as
+    // ours).  do_sweeps == 0: the caller may read the fields next, so they are folded into aux first -- before
+    // the selection, which re-bases the records the lean (p, rho) array is indexed by.
+    int rc = do_sweeps == 0 ? sph_ensure_aux(c) : 0;
+    rc = rc ? rc : sph_select_range(c, keep_first, keep_count);
     rc = rc ? rc : sph_append_records(c, srcL, nL);
     rc = rc ? rc : sph_append_records(c, srcR, nR);
-    rc = rc ? rc : sph_sort(c);
+    rc = rc ? rc : sort_no_fold(c);
     rc = rc ? rc : sph_layer_offsets_begin(c, layers, n_layers);
     if (!rc && ev) SPH_HIP(c, hipEventRecord(ev[1], c->stream));
     if (!rc && do_sweeps == 1) rc = sph_sweeps(c);
@@ -1118,12 +1135,23 @@ int32_t sph_dfsph_step(SphContext* c, int32_t n_steps, const int32_t* dynamic_id
         if (timing) SPH_HIP(c, hipEventRecord(ev[3], c->stream));
         rc = sphk_df_advect(c, true);                                // advect + enforce_boundary_3D(fluid)
         if (rc) return rc;
-        if (c->n_dyn_host > 0) { rc = sphk_rigid_solve_all(c, dynamic_ids, n_dynamic); if (rc) return rc; }  // solve_rigid_body()  sph_base.py:247-260
+        if (c->n_dyn_host > 0) { rc = sphk_rigid_solve_all(c, dynamic_ids, n_dynamic, false); if (rc) return rc; }  // solve_rigid_body()  sph_base.py:247-260
         if (timing) { SPH_HIP(c, hipEventRecord(ev[4], c->stream)); c->ev_used++; }
         c->df_stats.steps++;
     }
     return 0;
 }
+
+#ifdef SPH_PROFILE
+// profiling build only: the per-workgroup time line the brick sweeps left in the staging buffer (SPH_TS in sph_gather.hip)
+int32_t sph_profile_read(SphContext* c, void* host, size_t bytes) {
+    ENTER(c);
+    if (!host || bytes > c->stage_bytes) return sph_fail(c, SPH_E_INVALID, "sph_profile_read: bad size");
+    SPH_HIP(c, hipMemcpyAsync(host, c->stage, bytes, hipMemcpyDeviceToHost, c->stream));
+    SPH_HIP(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+#endif
 
 int32_t sph_slab_wait_pack(SphContext* c) {
     ENTER(c);

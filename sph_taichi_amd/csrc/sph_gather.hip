@@ -31,8 +31,19 @@
 // production build SPH_ABL is the constant 0: no mask argument, no branch, nothing to read past.
 #ifdef SPH_PROFILE
 #define SPH_ABL(d_, m_) ((d_).ablate & (m_))
+// Per-workgroup time line (profiling build, ablate bit 28 = the list-writing sweeps, bit 29 = the list-reading ones): wave
+// 0's first lane stamps the 100 MHz wall clock when the workgroup enters, after the step-A barrier (column table), after the
+// step-B barrier (tile staged), when ITS target is computed (before the finish) and when it leaves, plus where it ran
+// (HW_ID, XCC_ID) and how much it held -- 8 words per hardware block in d.prof_ts (sph_profile_read).  What the
+// table answers: how much of a workgroup's residence is staging / compute / finish, and whether the staging of one
+// resident workgroup is covered by the compute of its neighbours on the CU (tools/brick_timeline.py).
+#define SPH_TS(slot_)                                                                                         \
+    do {                                                                                                      \
+        if (ts_on && threadIdx.x == 0) d.prof_ts[(size_t)blockIdx.x * 8 + (slot_)] = wall_clock64();          \
+    } while (0)
 #else
 #define SPH_ABL(d_, m_) 0
+#define SPH_TS(slot_) do { } while (0)
 #endif
 
 // ---------------------------------------------------------------------------
@@ -697,7 +708,7 @@ __global__ __launch_bounds__(TPB) void k_gather_bvol_split(DevView d, const int*
 // The emission loop advances its offset once per hit with a SATURATING add (a target can have as many hits as the tile
 // has records; groups beyond the allocation are dropped by the buffer's range check, and an offset stuck at 2^32 - 1
 // stays out of range); the readers clamp the group index to the lane's last group, so every entry they fetch was written.
-#define SPH_BRICK_MAX_NZ 1000  // k_brick_list keeps five per-layer arrays per column group in LDS; taller grids take the cell walk
+#define SPH_BRICK_MAX_NZ 800  // k_brick_list (and the scatter kernel that hosts it) keeps five per-layer arrays per column group in LDS: 80 (nz + 1) bytes must stay inside the 64 KB a kernel gets without an opt-in; taller grids take the cell walk
 #define SPH_CNT_WALK 255  // gcnt sentinel: this target must take the exact global cell walk (its brick's shell overflowed the LDS tile)
 #define SPH_CNT_LIST_OVF 254  // same consequence, other cause: the target's own list outgrew LISTCAP
 #define SPH_VAR_EXACT 32      // internal template bit (not part of SPH_OPT_KERNEL_VARIANT): the SPH_OPT_EXACT_MATH instances
@@ -802,6 +813,16 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
     // XCD x takes the x-th eighth of the list, so neighbouring bricks share that XCD's L2 and -- because the list
     // holds work, not space -- all 8 XCDs are loaded evenly however the fluid sits in the tank.  The grid is sized
     // for the worst case (every brick non-empty); surplus blocks leave here.
+#ifdef SPH_PROFILE
+    const bool ts_on = d.prof_ts != nullptr && (d.ablate & (mode_reads_list<MODE>() ? (1 << 29) : (1 << 28))) != 0;
+    if (ts_on && threadIdx.x == 0) {
+        unsigned long long* row = d.prof_ts + (size_t)blockIdx.x * 8;
+        row[1] = row[2] = row[3] = row[4] = 0ull;
+        row[5] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);  // XCC_ID | HW_ID
+        row[6] = 0ull;
+    }
+    SPH_TS(0);
+#endif
     const int nbh = brick_count[0], nbl = brick_count[1];
     const int chunkh = (nbh + 7) >> 3, chunkl = (nbl + 7) >> 3;
     const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
@@ -857,9 +878,13 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
         if (lane == 63) { sColS[64] = incl; sTOff[64] = tincl; }
     }
     __syncthreads();
+    SPH_TS(1);
     const int T = sTOff[64];
     const int total = sColS[64];
     if (T == 0) return;
+#ifdef SPH_PROFILE
+    if (ts_on && threadIdx.x == 0) d.prof_ts[(size_t)blockIdx.x * 8 + 6] = ((unsigned long long)(unsigned)T << 32) | (unsigned)total;
+#endif
     const bool overflow = total > CFG::CAP;
 
     // round-0 target loads are issued here, together with the staging loads below, so that their latency is
@@ -938,6 +963,7 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
         }
     }
     __syncthreads();
+    SPH_TS(2);
 
     // ---- step C: targets ----
     for (int tn = tid; tn < T; tn += TPB) {
@@ -1042,12 +1068,14 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                 t.s0 += mVj * w;
             };
             // the hits of one mask become list entries `tagbase + bit` and (inline sweeps) density terms
+            unsigned last_e = 0u;  // the entry written last (pads the final group of four)
             auto emit_micro = [&](unsigned mask, unsigned tagbase, unsigned base16) {
                 cnt += __popc(mask);
                 while (mask) {
                     const unsigned bit = (unsigned)__ffs((int)mask) - 1u;
                     mask &= mask - 1u;
-                    if (!SPH_ABL(d, 2)) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(tagbase + bit), lrs, (int)(voff ^ lflip), 0, 0);
+                    last_e = tagbase + bit;
+                    if (!SPH_ABL(d, 2)) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)last_e, lrs, (int)(voff ^ lflip), 0, 0);
                     voff = __builtin_elementwise_add_sat(voff, 2u) | lmask;
                     if (INLINE_PHYS && !SPH_ABL(d, 32)) pair_term(base16 + (bit << 4));
                 }
@@ -1105,12 +1133,12 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                         emit_micro(filter_chunk(base, min(32, hi - base)), ((unsigned)ncol << 11) | (unsigned)base, (unsigned)base << 4);
                 }
             }
-            // The readers fetch whole groups of four: the rest of the last group is filled with the target's own entry
-            // (always a staged record; entries beyond the count are fetched, never paired).
+            // The readers fetch whole groups of four: the rest of the last group repeats the last entry written -- a staged
+            // record by construction (the target's own slot would not do: a target in flat cell 0 is never staged, the
+            // max(0, idx-1) quirk).  Entries beyond the count are fetched, never paired.
             if ((cnt & 3) && !SPH_ABL(d, 2)) {
-                const unsigned self_e = ((unsigned)col << 11) | ((unsigned)(gi - sColG[col]) & 2047u);
                 for (int u = cnt & 3; u < 4; ++u) {
-                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)self_e, lrs, (int)(voff ^ lflip), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b16((unsigned short)last_e, lrs, (int)(voff ^ lflip), 0, 0);
                     voff = __builtin_elementwise_add_sat(voff, 2u) | lmask;
                 }
             }
@@ -1226,8 +1254,10 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
             target_init<mode_walk<MODE>()>(d, t, Ai, Bi, Ei);
             gather_walk_global<mode_walk<MODE>()>(d, t, gi);
         }
+        SPH_TS(3);
         target_finish<MODE, V_EXACT>(d, t, gi, g, Ei);
     }
+    SPH_TS(4);
     }
 }
 

@@ -492,6 +492,9 @@ __device__ __forceinline__ void sum_partials_all(const DevView& d, const fx_t* _
     __syncthreads();
 }
 
+// ADVECT: the symplectic-Euler update of the dynamic rigid particles (WCSPH.py:143-149) rides in this kernel -- it is
+// what would otherwise be a launch of its own (k_advect_list) right before it, over the same list
+template <bool ADVECT>
 __global__ __launch_bounds__(TPB) void k_rigid_sum_all(DevView d, WallHi hi, const int* __restrict__ list, int n, BodyIds ids,
                                                        fx_t* __restrict__ part, int nblk) {
     __shared__ fx_t red[TPB / 64][16];
@@ -502,8 +505,13 @@ __global__ __launch_bounds__(TPB) void k_rigid_sum_all(DevView d, WallHi hi, con
         const int i = list[tix];
         float4 vf = d.vf[i];
         const int fl = __float_as_int(vf.w);
+        float4 xm = d.xm[i];
+        if (ADVECT && sph_is_dynamic_rigid(fl)) {
+            advect_one<false>(d, hi.v, xm, vf, d.acc[i]);
+            d.xm[i] = xm;
+            d.vf[i] = vf;
+        }
         if (sph_is_dynamic_rigid(fl) && (slot = body_slot(ids, sph_flags_object(fl))) >= 0) {
-            float4 xm = d.xm[i];
             wall_passes(d, hi.v, xm, vf, slot);
             const float mass = d.m_V0 * d.aux[i].y;
             v[0] = to_fx(d, mass); v[1] = to_fx(d, (double)(mass * xm.x)); v[2] = to_fx(d, (double)(mass * xm.y)); v[3] = to_fx(d, (double)(mass * xm.z));
@@ -859,11 +867,13 @@ int sphk_rigid_solve(SphContext* c, int object_id) {
 }
 
 // solve_rigid_body() (sph_base.py:247-260) for the dynamic bodies `ids` in the reference's order: three launches for all
-// of them when they fit the batch (<= 16 bodies, per-body rows of partials), else body by body
-int sphk_rigid_solve_all(SphContext* c, const int* ids, int n_ids) {
-    if (c->n_dyn_host <= 0 || n_ids <= 0) return 0;
+// of them when they fit the batch (<= 16 bodies, per-body rows of partials), else body by body.  advect_first: the
+// advect of the dynamic rigid particles (what sphk_advect_dyn_list does) happens here too, inside the first kernel
+int sphk_rigid_solve_all(SphContext* c, const int* ids, int n_ids, bool advect_first) {
+    if (c->n_dyn_host <= 0 || n_ids <= 0) return advect_first ? sphk_advect_dyn_list(c) : 0;
     const int n = c->n_dyn_host, nb = (n + TPB - 1) / TPB;
     if (!c->opt_rigid_batch || n_ids > SPH_MAX_BATCH_BODIES || (long long)nb * n_ids > c->rigid_part_blocks) {
+        if (advect_first) { int rc = sphk_advect_dyn_list(c); if (rc) return rc; }
         for (int k = 0; k < n_ids; ++k) {
             int rc = sphk_rigid_solve(c, ids[k]);
             rc = rc ? rc : sphk_enforce_boundary(c, SPH_MATERIAL_SOLID);
@@ -876,7 +886,8 @@ int sphk_rigid_solve_all(SphContext* c, const int* ids, int n_ids) {
     BodyIds b;
     b.n = n_ids;
     for (int k = 0; k < SPH_MAX_BATCH_BODIES; ++k) b.id[k] = k < n_ids ? ids[k] : -1;
-    hipLaunchKernelGGL(k_rigid_sum_all, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c), c->dyn_list, n, b, (fx_t*)c->rigid_part, nb);
+    if (advect_first) hipLaunchKernelGGL(k_rigid_sum_all<true>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c), c->dyn_list, n, b, (fx_t*)c->rigid_part, nb);
+    else hipLaunchKernelGGL(k_rigid_sum_all<false>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c), c->dyn_list, n, b, (fx_t*)c->rigid_part, nb);
     SPH_LAUNCH_CHECK(c);
     hipLaunchKernelGGL(k_rigid_A_all, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c), c->dyn_list, n, b, (fx_t*)c->rigid_part, nb);
     SPH_LAUNCH_CHECK(c);

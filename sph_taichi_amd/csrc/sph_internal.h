@@ -40,6 +40,7 @@ struct DevView {
     int exp_int;     // Tait exponent as a small integer (1..32) when it is one, else 0 (WCSPH.py:76)
 #ifdef SPH_PROFILE
     int ablate;      // profiling build only: bit0 skip phase 2, bit1 skip list write-out, bit2 skip phase 1, ... (sph_gather.hip)
+    unsigned long long* prof_ts;  // profiling build only: 8 words per hardware block of the brick sweeps (SPH_TS)
 #endif
     float grid_size, h, inv_h, d2, m_V0, rho0, stiffness, exponent, sigma, dt;
     float gx, gy, gz;
@@ -214,7 +215,7 @@ int sphk_advect_range(SphContext* c, int first, int count);
 int sphk_enforce_boundary(SphContext* c, int particle_type);
 int sphk_rigid_com(SphContext* c, int object_id, bool to_rest);
 int sphk_rigid_solve(SphContext* c, int object_id);
-int sphk_rigid_solve_all(SphContext* c, const int* ids, int n_ids);  // every dynamic body + the solid wall passes, batched
+int sphk_rigid_solve_all(SphContext* c, const int* ids, int n_ids, bool advect_first);  // every dynamic body + the solid wall passes, batched
 int sphk_extract(SphContext* c, int field, void* dst);
 int sphk_insert(SphContext* c, int field, const void* src);
 

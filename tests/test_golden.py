@@ -239,11 +239,13 @@ def test_hip_reproduces_big_reference_execution(path):
     solver.initialize()
     assert np.array_equal(ps.grid_ids.to_numpy(), z["initialized/grid_ids"])
     done = 0
+    mismatches = {}
     for n in (1, 10, 25, steps):
         solver.step(n - done)
         done = n
         gi = ps.grid_ids.to_numpy()
         same = np.array_equal(gi, z[f"step{n}/grid_ids"])
+        mismatches[str(n)] = int((gi != z[f"step{n}/grid_ids"]).sum())
         assert same or np.mean(gi != z[f"step{n}/grid_ids"]) <= 1e-3, f"cell ids after step {n}"
         if same:        # same cells => same (stable) order: compare in place
             assert scenes.rel_l2(ps.x.to_numpy(), z[f"step{n}/x"]) <= 1e-4, f"rel-L2(x) after step {n}"
@@ -254,3 +256,12 @@ def test_hip_reproduces_big_reference_execution(path):
     assert scenes.rel_l2(ps.v.to_numpy()[a], z[f"step{steps}/v"][b]) <= 2e-3
     assert scenes.rel_l2(ps.density.to_numpy()[a], z[f"step{steps}/density"][b]) <= 1e-3
     ps.close()
+    # (VERDICT r03 "weak" #4) the measured number of differing cell ids per kept stage, on record: gpurun_out -> profiles/
+    try:
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "big_fixture_cell_id_mismatches.json")
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        data = json.load(open(out)) if os.path.exists(out) else {}
+        data[os.path.basename(path)] = {"particles": int(z["initial/x"].shape[0]), "differing_cell_ids_after_step": mismatches}
+        json.dump(data, open(out, "w"), indent=1)
+    except OSError:
+        pass

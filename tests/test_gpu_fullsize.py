@@ -328,16 +328,15 @@ def test_c2_dragon_bath_to_floor_impact():
     assert p.max() > 1e3, "no pressure built up: the impact was not exercised"
     assert v[:, 1].max() > -0.5, "the bottom layers were not decelerated"
     # Derived fields.  Up to the impact they agree like the positions do (step 200: density 2e-7, v 4e-6, recorded in
-    # gpurun_out/parity_curves.json).  The impact itself amplifies ulp-level differences between two f32 evaluations
-    # of the same formulas (the oracle divides and takes square roots, the sweeps use v_rcp / v_rsq): with stiffness
-    # 5e4 and exponent 7 a relative density difference of 1e-7 is a pressure difference of ~4e-2 Pa on particles
-    # that are being stopped from 3 m/s within a few steps.  Measured at step 300 (r02g, every kernel variant alike):
-    # positions 7e-6 (budget 1e-4), density 1.0e-4, velocity 4.9e-3 in relative L2.
-    curves = json.load(open(os.path.join(ROOT, "gpurun_out", "parity_curves.json")))["c2_dragon_bath"]
-    rho200, v200 = dict(curves["rel_l2_density"])[200], dict(curves["rel_l2_v"])[200]
-    assert rho200 <= 1e-5 and v200 <= 1e-4, f"before the impact: density {rho200:.2e}, v {v200:.2e}"
-    assert scenes.rel_l2(scenes.ps_by_pid(ps, "density"), o.by_pid("density")) <= 5e-4
-    assert scenes.rel_l2(scenes.ps_by_pid(ps, "v"), o.by_pid("v")) <= 2e-2
+    # gpurun_out/parity_curves.json).  The impact amplifies ulp-level differences between ANY two f32 evaluations of the
+    # same formulas: with stiffness 5e4 and exponent 7 a relative density difference of 1e-7 is a pressure difference of
+    # ~4e-2 Pa on particles that are being stopped from 3 m/s within a few steps.  Round 4 measured what that floor is
+    # (profiles/r04_parity_fastmath_ab.json): at step 300 the CPU restatement against ITSELF with nothing changed but the
+    # order in which neighbours are visited differs by x 5.1e-6 / v 3.7e-3 / density 7.6e-5; the HIP path from it by
+    # 6.7e-6 / 4.2e-3 / 9.5e-5 (6.0e-6 / 3.8e-3 / 7.8e-5 with SPH_OPT_EXACT_MATH: IEEE sqrt and divide instead of
+    # v_rsq / v_rcp are worth ~10 % of it, not the bulk round 3 assumed).  Bounds = 2 x those measurements.
+    assert scenes.rel_l2(scenes.ps_by_pid(ps, "density"), o.by_pid("density")) <= 2e-4
+    assert scenes.rel_l2(scenes.ps_by_pid(ps, "v"), o.by_pid("v")) <= 1e-2
     ps.close()
 
 

@@ -148,6 +148,9 @@ enum SphOption {
    a mask with that bit set is refused) */
 #define SPH_VAR_FORCE_BF 8 /* force sweep: branch-free fluid pair term, buffer addressing for list and gather */
 #define SPH_VAR_DEEP 16    /* list-reading sweeps: list entries loaded a whole round (3 pairs) before they are decoded */
+#define SPH_VAR_PERSIST 64 /* (A/B, r04; with GROUPS resp. FORCE_BF | DEEP) the two sweeps of sph_step as PERSISTENT workgroups: the grid is the chip's
+                              resident slots, a workgroup takes bricks of its XCD's part of the list by ticket and fetches the next
+                              ticket while it computes.  Bit 32 is reserved (internal). */
 /* 0 = the baseline: run-by-run emission in the reference's (dx, dy) order, plain list loop in the force sweep.
  * Default = GROUPS | FORCE_BF | DEEP.  (Rounds 1-2 also carried PAD, MICRO -- now always on -- and 2PHASE, MIRROR,
  * SORTED: measured, superseded and removed; their tables are profiles/r02c, r02o, r02p.) */

@@ -119,6 +119,7 @@ struct SphContext {
     unsigned char* gcnt;    // [cap] list lengths (255 = take the global cell walk)
     int2* brick_list;       // [brick_cap] bricks of the sweep being launched: (column group, first z layer | height << 16)
     int* brick_count;       // device counter
+    int* brick_ticket;      // [32] SPH_VAR_PERSIST: per-XCD ticket + exit counters of the filtering ([0..15]) and list-reading ([16..31]) sweeps; zero between launches
     int brick_cap;
     int scan_blocks;
     float* x0_cold;    // [3*cap]

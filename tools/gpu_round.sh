@@ -64,3 +64,10 @@ if has nativemp; then   # only the multi-process native-exchange tests (tests/fa
   timeout 600 python -m pytest tests/test_distributed.py -m gpu -x -q -k "native_exchange" --durations=10 > $OUT/pytest_native_mp.log 2>&1; echo "native mp rc=$?"
   tail -n 25 $OUT/pytest_native_mp.log
 fi
+if has timeline; then   # per-workgroup time line of the two brick sweeps (profiling build)
+  timeout 600 python tools/brick_timeline.py --out $OUT/brick_timeline.txt > $OUT/brick_timeline.log 2>&1; echo "timeline rc=$?"; grep -v amdgpu $OUT/brick_timeline.log | tail -n 40
+fi
+if has bodies; then     # the default line's with_bodies object alone (C3 with immersed bodies)
+  timeout 300 python bench.py --steps 100 --warmup 10 --cpu-steps 0 --settled-after 0 --min-seconds 0 > $OUT/bench_with_bodies.json 2>> $OUT/bench.err
+  python -c "import json;d=json.load(open('$OUT/bench_with_bodies.json'));print('with_bodies', json.dumps(d.get('with_bodies'))[:900])"
+fi

@@ -372,6 +372,21 @@ def main():
                       "simulated_time_per_wall_second": round(args.steps / dt * DFSPH_DT, 3)},
             "roofline": None,
         }
+        # The step is ~37 neighbour sweeps over unchanged positions; all but the first read the neighbour lists.  Algorithmic
+        # bytes of ONE list-reading Jacobi sweep (DFSPH.py:285-321 / 356-394), minimal-fused like SURVEY 8(d)'s WCSPH rows: read
+        # x 12, v 12, (factor, density_adv) 8, m_V 4, material / is_dynamic 8; write v 12 => 56 N + 4 G.  Duration = the mean
+        # over ALL sweeps of the step (HIP events of the neighbour + force buckets / sweeps, read-backs included), so the
+        # fraction is a lower bound for the Jacobi sweeps themselves (111-113 us in the kernel trace).
+        ms_sweep = line["dfsph"]["ms_per_sweep"]
+        ab = 56.0 * N + 4.0 * G
+        if ms_sweep > 0:
+            ach = ab / (ms_sweep * 1e-3) / 1e9
+            line["roofline"] = {"kernel": "k_gather_brick<GM_DF_*_ITER_U> (list-reading Jacobi sweep; mean over the step's sweeps)",
+                                "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "alg_bytes_per_launch": ab,
+                                "avg_launch_ms": ms_sweep,
+                                "note": "gather sweeps are VALU- / vector-memory-bound, not HBM-bound (DESIGN.md section 3); no PMC pass "
+                                        "exists for the DFSPH kernels, so traffic is null"}
         ps.close()
         line["cpu_baseline"] = cpu_baseline(sd, args.cpu_steps) if args.cpu_steps > 0 else None
         print(json.dumps(line), flush=True)
@@ -492,7 +507,7 @@ def main():
     dom_ms = dk["avg_launch_ms"]
     # VALU roofline of the same kernel.  Peak issue rate: 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction
     # (MI355X_MICROARCH.md; measured here 0.85-0.9 G wave-instructions/s per SIMD at the clock the chip sustains,
-    # profiles/r02a_ubench_valu_table1.txt -- and half / a quarter of that for the 4- and 8-cycle opcode classes).
+    # profiles/archive/r02a_ubench_valu_table1.txt -- and half / a quarter of that for the 4- and 8-cycle opcode classes).
     # Useful work: SURVEY 8d's ~2.3 kFLOP (density) / ~4.6 kFLOP (force) per particle against 157.3 TFLOP/s.
     roofline_valu = {"kernel": dominant, "unit": "G wave-instructions/s", "peak": VALU_PEAK_GINST,
                      "peak_measured_full_rate_ops": round(1024 * 0.875, 1),

@@ -144,16 +144,16 @@ enum SphOption {
 #define SPH_VAR_GROUPS 1   /* density: all nine runs filtered first (masks in registers), hits emitted centre run / edge runs / corner
                               runs, each group by descending hit count */
 /* (bit 2 was SPH_VAR_RING, the per-lane LDS ring of hit masks with ONE balanced emission loop per lane: built, parity-green,
-   slower than GROUPS -- profiles/r03f_variants_partition_x_emission.json, DESIGN.md 4.5 -- and removed after commit 1bbd9b5;
+   slower than GROUPS -- profiles/archive/r03f_variants_partition_x_emission.json, DESIGN.md 4.5 -- and removed after commit 1bbd9b5;
    a mask with that bit set is refused) */
 #define SPH_VAR_FORCE_BF 8 /* force sweep: branch-free fluid pair term, buffer addressing for list and gather */
 #define SPH_VAR_DEEP 16    /* list-reading sweeps: list entries loaded a whole round (3 pairs) before they are decoded */
-#define SPH_VAR_PERSIST 64 /* (A/B, r04; with GROUPS resp. FORCE_BF | DEEP) the two sweeps of sph_step as PERSISTENT workgroups: the grid is the chip's
-                              resident slots, a workgroup takes bricks of its XCD's part of the list by ticket and fetches the next
-                              ticket while it computes.  Bit 32 is reserved (internal). */
+/* (r04: bit 64 was SPH_VAR_PERSIST -- both sweeps as PERSISTENT workgroups, grid = the chip's resident slots, bricks taken by
+   per-XCD TICKETS with the next ticket fetched while computing: built, parity-green, slower like round 2's static walk (density
+   +17 %, force +25 %: profiles/r04c_variants_persistent_tickets.json, DESIGN_HISTORY.md) and removed after commit e7af346) */
 /* 0 = the baseline: run-by-run emission in the reference's (dx, dy) order, plain list loop in the force sweep.
  * Default = GROUPS | FORCE_BF | DEEP.  (Rounds 1-2 also carried PAD, MICRO -- now always on -- and 2PHASE, MIRROR,
- * SORTED: measured, superseded and removed; their tables are profiles/r02c, r02o, r02p.) */
+ * SORTED: measured, superseded and removed; their tables are profiles/archive/r02c, r02o, r02p.) */
 
 /* ms accumulated by sph_step since the last sph_reset_timings (HIP events on
  * the context's stream).  sort = K1+K2+K3 (initialize_particle_system),

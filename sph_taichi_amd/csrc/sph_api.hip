@@ -172,7 +172,6 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     rc = rc ? rc : alloc_dev(c, (void**)&c->brick_count, 16);
     rc = rc ? rc : alloc_dev(c, (void**)&c->brick_list2, (size_t)c->brick_cap * 8);
     rc = rc ? rc : alloc_dev(c, (void**)&c->brick_count2, 16);
-    rc = rc ? rc : alloc_dev(c, (void**)&c->brick_ticket, 32 * sizeof(int));
     const size_t cold = params->cold_capacity > 0 ? (size_t)params->cold_capacity : cap;
     if (cold < cap) { sph_destroy(c); return sph_fail(nullptr, SPH_E_INVALID, "sph_create: cold_capacity < capacity"); }
     c->cold_cap = (int)cold;
@@ -210,7 +209,7 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     sph_invalidate_lists(c);
     c->opt_uniform = -1; c->uniform_state = -1; c->m_uniform = 0.0f;  // SPH_OPT_UNIFORM_FLUID: auto
     c->opt_variant = SPH_VAR_DEFAULT;
-    if (const char* e = getenv("SPH_KERNEL_VARIANT")) c->opt_variant = atoi(e) & (25 | 64);  // A/B aid: the default mask of every context of this process
+    if (const char* e = getenv("SPH_KERNEL_VARIANT")) c->opt_variant = atoi(e) & 25;  // A/B aid: the default mask of every context of this process
     memset(&c->df_stats, 0, sizeof(c->df_stats));
     c->df.enable_divergence_solver = 1; c->df.m_max_iterations_v = 100; c->df.m_max_iterations = 100;  // DFSPH.py:12-20
     c->df.fluid_particle_num = 0; c->df.m_eps = 1e-5f; c->df.reserved_ = 0.0f; c->df.max_error_V = 0.1; c->df.max_error = 0.05;
@@ -224,7 +223,7 @@ int32_t sph_destroy(SphContext* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->xm[0], c->xm[1], c->vf[0], c->vf[1], c->aux[0], c->aux[1], c->key[0], c->key[1], c->eos, c->stg, c->gat, c->acc,
                     c->acc_tmp, c->cell_buf[0], c->cell_buf[1], c->rank_off, c->idx_unstable, c->scan_sums, c->x0_cold, c->color_cold,
-                    c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->acc_fx, c->rigid_part, c->rigid_R, c->df_err, c->df_part, c->stage, c->glist, c->gcnt, c->brick_list, c->brick_count, c->brick_list2, c->brick_count2, c->brick_ticket};
+                    c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->acc_fx, c->rigid_part, c->rigid_R, c->df_err, c->df_part, c->stage, c->glist, c->gcnt, c->brick_list, c->brick_count, c->brick_list2, c->brick_count2};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < SPH_MAX_TIMED_STEPS; ++s)
         for (int k = 0; k < 5; ++k) if (c->ev[s][k]) (void)hipEventDestroy(c->ev[s][k]);
@@ -258,7 +257,7 @@ int32_t sph_set_option(SphContext* c, int32_t option, int32_t value) {
         case SPH_OPT_RIGID_BATCH: c->opt_rigid_batch = value ? 1 : 0; return 0;
         case SPH_OPT_EXACT_MATH: c->opt_exact_math = value ? 1 : 0; sph_invalidate_lists(c); return 0;
         case SPH_OPT_KERNEL_VARIANT:
-            if (value < -1 || value > 127 || (value > 0 && (value & (2 | 4 | 32)))) return sph_fail(c, SPH_E_INVALID, "kernel variant must be -1 (default) or a mask of SPH_VAR_*");
+            if (value < -1 || value > 31 || (value > 0 && (value & 6))) return sph_fail(c, SPH_E_INVALID, "kernel variant must be -1 (default) or a mask of SPH_VAR_*");
             c->opt_variant = value < 0 ? SPH_VAR_DEFAULT : value;
             sph_invalidate_lists(c);
             return 0;

@@ -361,7 +361,7 @@ __device__ __forceinline__ void pair_physics(const DevView& d, Target& t, float 
 // had been rejected (particle_system.py:385), and the self pair (r = 0) multiplies finite coefficients by r = 0.  Only a
 // solid neighbour still needs the accept test (its reaction is scattered with atomics).
 // a uniform value held in a VGPR: on gfx950 a VALU instruction with an SGPR source issues at half rate
-// (profiles/r02b_ubench_valu_table2.txt: v_fma_f32 with one SGPR operand 4.4 cycles, all-VGPR 2.6)
+// (profiles/archive/r02b_ubench_valu_table2.txt: v_fma_f32 with one SGPR operand 4.4 cycles, all-VGPR 2.6)
 __device__ __forceinline__ float sph_in_vgpr(float x) { float r; asm("v_mov_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
 __device__ __forceinline__ unsigned sph_in_vgpr(unsigned x) { unsigned r; asm("v_mov_b32 %0, %1" : "=v"(r) : "v"(x)); return r; }
 // The constants of the pair term sit in VGPRs (sph_in_vgpr below).
@@ -712,7 +712,6 @@ __global__ __launch_bounds__(TPB) void k_gather_bvol_split(DevView d, const int*
 #define SPH_CNT_WALK 255  // gcnt sentinel: this target must take the exact global cell walk (its brick's shell overflowed the LDS tile)
 #define SPH_CNT_LIST_OVF 254  // same consequence, other cause: the target's own list outgrew LISTCAP
 #define SPH_VAR_EXACT 32      // internal template bit (not part of SPH_OPT_KERNEL_VARIANT): the SPH_OPT_EXACT_MATH instances
-#define SPH_PERSIST_WG_PER_CU(reads_list_) ((reads_list_) ? 5 : 4)
 
 template <int MODE>
 __host__ __device__ constexpr bool mode_writes_list() { return MODE == GM_DENSITY_EOS || MODE == GM_DF_DENSITY; }
@@ -788,16 +787,9 @@ template <int MODE, class CFG, int VAR = 0>
 __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gather_brick(DevView d, int nby, const int2* __restrict__ brick_list,
                                                       const int* __restrict__ brick_count,
                                                       unsigned short* __restrict__ glist,
-                                                      unsigned char* __restrict__ gcnt, int cap, int list_cap, int lshift,
-                                                      int* __restrict__ ticket) {
+                                                      unsigned char* __restrict__ gcnt, int cap, int list_cap, int lshift) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool HAS_W = !mode_reads_list<MODE>();
-    // SPH_VAR_PERSIST: the grid is the chip's resident slots; a workgroup walks its XCD's part of the list by TICKET
-    // (dynamic, unlike the static stride of round 2's persistent attempt) and takes the next ticket while it computes,
-    // so that the brick entry is there when the tile is free again: per brick one dependent load phase less (the
-    // counts + entry of a fresh workgroup) and no dispatch gap between two workgroups of a slot.
-    constexpr bool V_PERSIST = (VAR & SPH_VAR_PERSIST) != 0;
-    __shared__ int s_next;
     constexpr bool V_GROUPS = (VAR & SPH_VAR_GROUPS) != 0 && !mode_reads_list<MODE>();
     constexpr bool V_BF = (VAR & SPH_VAR_FORCE_BF) != 0 && MODE == GM_FORCE_FUSED_U;
     constexpr bool V_DEEP = (VAR & SPH_VAR_DEEP) != 0 && mode_reads_list<MODE>();
@@ -833,29 +825,15 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
 #endif
     const int nbh = brick_count[0], nbl = brick_count[1];
     const int chunkh = (nbh + 7) >> 3, chunkl = (nbl + 7) >> 3;
-    const int xcd = (int)(blockIdx.x & 7);
-    int slot = (int)(blockIdx.x >> 3);
-    if (V_PERSIST) {
-        if (tid == 0) s_next = atomicAdd(&ticket[xcd], 1);
-        __syncthreads();
-        slot = s_next;
-    }
-    for (;;) {
-    if (V_PERSIST && slot >= chunkh + chunkl) {
-        // out of work: the last workgroup of this XCD to get here leaves the counters at zero for the next launch
-        if (tid == 0 && atomicAdd(&ticket[8 + xcd], 1) == (int)(gridDim.x >> 3) - 1) { ticket[xcd] = 0; ticket[8 + xcd] = 0; }
-        return;
-    }
-    bool brick_done = false;
-    do {
+    const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
     int2 brick;
     if (slot < chunkh) {  // heavy bricks first (blocks are dispatched in blockIdx order) ...
         const int kb = xcd * chunkh + slot;
-        if (kb >= nbh) { if (V_PERSIST) break; return; }
+        if (kb >= nbh) return;
         brick = brick_list[kb];
     } else {  // ... the light ones fill the tail
         const int kb = xcd * chunkl + (slot - chunkh);
-        if (slot - chunkh >= chunkl || kb >= nbl) { if (V_PERSIST) break; return; }
+        if (slot - chunkh >= chunkl || kb >= nbl) return;
         brick = brick_list[list_cap - 1 - kb];
     }
     {
@@ -903,7 +881,7 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
     SPH_TS(1);
     const int T = sTOff[64];
     const int total = sColS[64];
-    if (T == 0) { if (V_PERSIST) break; return; }
+    if (T == 0) return;
 #ifdef SPH_PROFILE
     if (ts_on && threadIdx.x == 0) d.prof_ts[(size_t)blockIdx.x * 8 + 6] = ((unsigned long long)(unsigned)T << 32) | (unsigned)total;
 #endif
@@ -986,8 +964,6 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
     }
     __syncthreads();
     SPH_TS(2);
-    int next_ticket = 0;
-    if (V_PERSIST && tid == 0) next_ticket = atomicAdd(&ticket[xcd], 1);  // (returns while this brick is computed)
 
     // ---- step C: targets ----
     for (int tn = tid; tn < T; tn += TPB) {
@@ -1282,16 +1258,6 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
         target_finish<MODE, V_EXACT>(d, t, gi, g, Ei);
     }
     SPH_TS(4);
-    if (V_PERSIST && tid == 0) s_next = next_ticket;
-    brick_done = true;
-    }
-    } while (0);
-    if (!V_PERSIST) return;
-    // (an empty slot, or a brick without targets of this sweep: the ticket was not taken yet)
-    if (!brick_done && tid == 0) s_next = atomicAdd(&ticket[xcd], 1);
-    __syncthreads();  // every wave is through with the tile; thread 0's ticket is published
-    slot = s_next;
-    __syncthreads();  // ... and read by everybody before thread 0 can publish the next one
     }
 }
 
@@ -1478,16 +1444,8 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
             c->bricks_valid = true;
         }
     }
-    int* ticket = nullptr;
-    int launch_grid = grid;
-    if constexpr ((VAR & SPH_VAR_PERSIST) != 0) {
-        // the chip's resident slots: 8 XCDs x 32 CUs x (4 | 5) workgroups; two counter sets (filtering / list-reading sweeps),
-        // each left at zero by the launch that used it
-        ticket = c->brick_ticket + (mode_reads_list<MODE>() ? 16 : 0);
-        launch_grid = 8 * 32 * SPH_PERSIST_WG_PER_CU(mode_reads_list<MODE>());
-    }
-    hipLaunchKernelGGL((k_gather_brick<MODE, CFG, VAR>), dim3(launch_grid), dim3(TPB), bytes, st, d, nby, blist, bcount, c->glist,
-                       c->gcnt, c->cap, c->brick_cap, c->glist_shift, ticket);
+    hipLaunchKernelGGL((k_gather_brick<MODE, CFG, VAR>), dim3(grid), dim3(TPB), bytes, st, d, nby, blist, bcount, c->glist,
+                       c->gcnt, c->cap, c->brick_cap, c->glist_shift);
     SPH_LAUNCH_CHECK(c);
     return 0;
 }
@@ -1496,17 +1454,12 @@ template <int MODE>
 static int launch_brick(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, int hi2 = 0) {
     // SPH_OPT_KERNEL_VARIANT: the instances of the two sweeps of the fused WCSPH step (include/sph_hip.h)
     const int var = c->opt_variant;
-    // SPH_VAR_PERSIST (A/B): only for the single-stream sweeps of sph_step (one launch per counter set at a time)
-    const bool persist = (var & SPH_VAR_PERSIST) != 0 && !c->use_side && lo < 0;
     if constexpr (MODE == GM_DENSITY_EOS) {
         if (c->opt_exact_math) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS | SPH_VAR_EXACT>(c, lo, hi, lo2, hi2);
-        if (persist && (var & SPH_VAR_GROUPS)) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS | SPH_VAR_PERSIST>(c, lo, hi, lo2, hi2);
         if (var & SPH_VAR_GROUPS) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS>(c, lo, hi, lo2, hi2);
     }
     if constexpr (MODE == GM_FORCE_FUSED_U) {
         if (c->opt_exact_math) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_EXACT>(c, lo, hi, lo2, hi2);
-        if (persist && (var & (SPH_VAR_FORCE_BF | SPH_VAR_DEEP)) == (SPH_VAR_FORCE_BF | SPH_VAR_DEEP))
-            return launch_brick_cfg<MODE, Cfg0, SPH_VAR_FORCE_BF | SPH_VAR_DEEP | SPH_VAR_PERSIST>(c, lo, hi, lo2, hi2);
         switch (var & (SPH_VAR_FORCE_BF | SPH_VAR_DEEP)) {
             case SPH_VAR_FORCE_BF: return launch_brick_cfg<MODE, Cfg0, SPH_VAR_FORCE_BF>(c, lo, hi, lo2, hi2);
             case SPH_VAR_DEEP: return launch_brick_cfg<MODE, Cfg0, SPH_VAR_DEEP>(c, lo, hi, lo2, hi2);
@@ -1553,7 +1506,7 @@ static int launch_df(SphContext* c) {
         return launch_simple<MODE>(c, nullptr, c->N);
     }
     // (the group-sorted emission and the early entry loads of SPH_VAR_DEEP do nothing measurable for these sweeps: DFSPH
-    // step 3.46 vs 3.51 ms with DEEP, profiles/r02g -- their pair terms gather 4 bytes, not a 16-byte record)
+    // step 3.46 vs 3.51 ms with DEEP, profiles/archive/r02g -- their pair terms gather 4 bytes, not a 16-byte record)
     int rc = launch_brick_cfg<MODE, Cfg0>(c);
     if (!rc && mode_writes_list<MODE>()) { c->lists_valid = true; c->gcnt_written = true; c->stg_kind = 2; c->k_kind = 0; }
     if (!rc && MODE == GM_DF_DENSITY_CHANGE) c->k_kind = 1;

@@ -25,9 +25,9 @@
 #define SPH_MATERIAL_SOLID 0  // particle_system.py:30
 #define SPH_MATERIAL_FLUID 1  // particle_system.py:31
 #define SPH_MAX_TIMED_STEPS 128
-#define SPH_GLIST_ROWS 96  // list entries allocated per particle (24 groups of four); lists up to LISTCAP = 95 entries (developed dam-break flows reach 58, profiles/r03i)
+#define SPH_GLIST_ROWS 96  // list entries allocated per particle (24 groups of four); lists up to LISTCAP = 95 entries (developed dam-break flows reach 58, profiles/archive/r03i)
 #define SPH_DF_ERR_BLOCKS 512
-#define SPH_VAR_DEFAULT (SPH_VAR_GROUPS | SPH_VAR_FORCE_BF | SPH_VAR_DEEP)  // SPH_OPT_KERNEL_VARIANT when the caller does not choose: the fastest rows of profiles/r03f_variants_partition_x_emission.json (density) and r02g_variants_force.json (force)
+#define SPH_VAR_DEFAULT (SPH_VAR_GROUPS | SPH_VAR_FORCE_BF | SPH_VAR_DEEP)  // SPH_OPT_KERNEL_VARIANT when the caller does not choose: the fastest rows of profiles/archive/r03f_variants_partition_x_emission.json (density) and r02g_variants_force.json (force)
 
 struct DevView {
     int N, G;
@@ -119,7 +119,6 @@ struct SphContext {
     unsigned char* gcnt;    // [cap] list lengths (255 = take the global cell walk)
     int2* brick_list;       // [brick_cap] bricks of the sweep being launched: (column group, first z layer | height << 16)
     int* brick_count;       // device counter
-    int* brick_ticket;      // [32] SPH_VAR_PERSIST: per-XCD ticket + exit counters of the filtering ([0..15]) and list-reading ([16..31]) sweeps; zero between launches
     int brick_cap;
     int scan_blocks;
     float* x0_cold;    // [3*cap]

@@ -524,6 +524,37 @@ def test_native_exchange_reports_a_missing_peer_instead_of_hanging(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("transport", ["torch", "native"])
+def test_bench_two_ranks_on_one_gpu(transport, tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank) -- here with both ranks
+    on the one GPU there is (SPH_DIST_BACKEND=gloo), once over the torch transport and once over NativeTransport through
+    the librccl stand-in, negotiated collectively: the tiled weak-scaling line AND BASELINE.json's config 5 (`c4_dambreak`,
+    shrunk by SPH_C4_SCALE so that it fits a test) with re-cut, a settled state, per-rank owned counts and conservation."""
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, SPH_DIST_BACKEND="gloo", SPH_C4_SCALE="0.2", SPH_TRANSPORT=transport)
+    if transport == "native":
+        env.update(_fake_rccl_env(slot_bytes=1 << 20))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3",
+           "--settled-after", "60", "--preheat-ms", "0"]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["particles"] == 2 * 1_747_584
+    assert d["config"]["transport"] == ("NativeTransport" if transport == "native" else "TorchTransport"), d["config"]
+    assert sum(d["config"]["particles_owned_per_rank"]) == d["config"]["particles"]
+    c4 = d["c4_dambreak"]
+    assert "error" not in c4, c4
+    assert c4["conserved"] and c4["recut_every"] == 10 and c4["from_rest"]["value"] > 0 and c4["settled"]["value"] > 0
+    assert sum(c4["owned_end"]) == c4["particles"] and len(c4["owned_end"]) == 2
+    assert c4["imbalance_end"] <= 1.25, c4
+    if transport == "native":
+        assert c4["transport"] == "NativeTransport" and c4["halo_device_ms"] >= 0.0 and "halo_device" in d["breakdown_ms"]
+
+
+@pytest.mark.gpu
 def test_conservation_guard_raises_when_a_particle_outruns_the_halo():
     """a particle that crosses more than one cell layer in a step is dropped (or duplicated) by the
     exchange; the guard must turn that into an error instead of a silently different fluid."""

@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 i=0
 for ARGS in "$@"; do
   i=$((i+1))
-  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof$i -o prof --output-format csv -- python $R/bench.py --cpu-steps 0 $ARGS > $OUT/rocprof$i.log 2>&1 )
+  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof$i -o prof --output-format csv -- python $R/bench.py --cpu-steps 0 --with-bodies 0 $ARGS > $OUT/rocprof$i.log 2>&1 )
   f=$(find $OUT/prof$i -name "*kernel_stats.csv" | head -1)
   t=$(find $OUT/prof$i -name "*kernel_trace.csv" | head -1)
   echo "== $ARGS"

@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $R/bench.py --steps 20 --warmup 3 --cpu-steps 0 --min-seconds 0 --settled-after 0 $@"
+BENCH="python $R/bench.py --steps 20 --warmup 3 --cpu-steps 0 --min-seconds 0 --settled-after 0 --with-bodies 0 $@"
 run() { # name counters...
   n=$1; shift
   timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -o p -- $BENCH > $OUT/$n.log 2>&1

@@ -33,13 +33,14 @@ if has kstats; then
 fi
 if has bench; then
   timeout 300 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 1200 $OUT/bench_default.json; echo
-  timeout 200 python bench.py --steps 20 --warmup 5 --cpu-steps 0 > $OUT/bench_driver_args.json 2>> $OUT/bench.err
+  timeout 200 python bench.py --steps 20 --warmup 5 --cpu-steps 0 --with-bodies 0 > $OUT/bench_driver_args.json 2>> $OUT/bench.err
   for w in c1_dambreak_262k c2_dragon_bath c3_armadillo_equiv; do
     timeout 200 python bench.py --steps 100 --warmup 10 --cpu-steps 0 --workload $w --settled-after 0 --min-seconds 0 > $OUT/bench_$w.json 2>> $OUT/bench.err
   done
   timeout 200 python bench.py --steps 100 --warmup 10 --cpu-steps 0 --workload c1_dambreak_262k --settle 2500 --settled-after 0 > $OUT/bench_c1_developed.json 2>> $OUT/bench.err
   timeout 300 python bench.py --steps 30 --warmup 3 --cpu-steps 0 --solver dfsph > $OUT/bench_dfsph_c3p.json 2>> $OUT/bench.err
-  for f in driver_args c1_dambreak_262k c2_dragon_bath c3_armadillo_equiv c1_developed dfsph_c3p; do python -c "import json;d=json.load(open('$OUT/bench_$f.json'));print('$f',d['value'],d['ms_per_step'],d['breakdown_ms'])"; done
+  timeout 400 python bench.py --steps 50 --warmup 10 --cpu-steps 0 --workload c4_dambreak --settled-after 2500 --min-seconds 0 --max-reps 1 > $OUT/bench_c4_dambreak_one_gpu.json 2>> $OUT/bench.err
+  for f in driver_args c1_dambreak_262k c2_dragon_bath c3_armadillo_equiv c1_developed dfsph_c3p c4_dambreak_one_gpu; do python -c "import json;d=json.load(open('$OUT/bench_$f.json'));print('$f',d['value'],d['ms_per_step'],d['breakdown_ms'])"; done
 fi
 if has variants; then
   timeout 600 python tools/variant_sweep.py --variants 25,0 --shapes 1,0 --steps 60 --settled-steps 80 --out $OUT/variants_partition_x_emission.json > $OUT/variants.log 2>&1

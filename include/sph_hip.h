@@ -276,7 +276,8 @@ int32_t sph_slab_advance(SphContext* ctx, int32_t keep_first, int32_t keep_count
  * [br_lo,br_hi); the two halo packers (records [firstL,+nL) / [firstR,+nR) advanced by this step's Euler + wall
  * update, written to dstL / dstR, arrays untouched); an event; the force sweep of the remaining owned layers; the
  * in-place advect.  sph_slab_wait_pack blocks until the packers are done -- the caller starts the exchange while
- * the interior force sweep is still running. */
+ * the interior force sweep is still running.  (With the advect fused into the interior sweep's finish the interior
+ * particles' `acceleration` field is not materialised by this call: only the boundary sets' is, for the packers.) */
 int32_t sph_slab_forces(SphContext* ctx, int32_t bl_lo, int32_t bl_hi, int32_t br_lo, int32_t br_hi,
                         int32_t firstL, int32_t nL, void* dstL, int32_t firstR, int32_t nR, void* dstR);
 int32_t sph_slab_wait_pack(SphContext* ctx);

@@ -901,8 +901,12 @@ int32_t sph_slab_forces(SphContext* c, int32_t bl_lo, int32_t bl_hi, int32_t br_
     // (ghost records are not advected at all: the exchange replaces them)
     const bool fuse = c->uniform_state == 1 && c->stg_kind == 1 && c->lists_valid && c->opt_no_dynamic;
     c->fuse_advect = fuse ? 1 : 0;
+    // (an interior target's acceleration is consumed by the advect in the same finish and by nobody else -- the packers
+    // read the BOUNDARY sets' -- so, as inside sph_step, it is not written out: 16 B per particle and step less)
+    c->skip_acc = fuse ? 1 : 0;
     rc = sphk_gather_layers(c, GM_FORCE_FUSED, bl_hi, br_lo, 0, 0);
     c->fuse_advect = 0;
+    c->skip_acc = 0;
     if (rc) return rc;
     if (!no_boundary) SPH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pack, 0));  // the packers read what the advect overwrites
     hipEvent_t* ev = c->slab_ev_open ? c->ev[c->ev_used] : nullptr;

@@ -495,8 +495,8 @@ __device__ __forceinline__ void sum_partials_all(const DevView& d, const fx_t* _
 // ADVECT: the symplectic-Euler update of the dynamic rigid particles (WCSPH.py:143-149) rides in this kernel -- it is
 // what would otherwise be a launch of its own (k_advect_list) right before it, over the same list
 template <bool ADVECT>
-__global__ __launch_bounds__(TPB) void k_rigid_sum_all(DevView d, WallHi hi, const int* __restrict__ list, int n, BodyIds ids,
-                                                       fx_t* __restrict__ part, int nblk) {
+__device__ __forceinline__ void rigid_phase_sum(const DevView& d, const WallHi& hi, const int* __restrict__ list, int n, const BodyIds& ids,
+                                                fx_t* __restrict__ part, int nblk) {
     __shared__ fx_t red[TPB / 64][16];
     const int tix = blockIdx.x * TPB + threadIdx.x;
     int slot = -1;
@@ -522,9 +522,14 @@ __global__ __launch_bounds__(TPB) void k_rigid_sum_all(DevView d, WallHi hi, con
         block_store_partials_at<4>(s, part + (size_t)b * nblk * RIGID_PART, 0, red);
     }
 }
+template <bool ADVECT>
+__global__ __launch_bounds__(TPB) void k_rigid_sum_all(DevView d, WallHi hi, const int* __restrict__ list, int n, BodyIds ids,
+                                                       fx_t* __restrict__ part, int nblk) {
+    rigid_phase_sum<ADVECT>(d, hi, list, n, ids, part, nblk);
+}
 
-__global__ __launch_bounds__(TPB) void k_rigid_A_all(DevView d, WallHi hi, const int* __restrict__ list, int n, BodyIds ids,
-                                                     fx_t* __restrict__ part, int nblk) {
+__device__ __forceinline__ void rigid_phase_A(const DevView& d, const WallHi& hi, const int* __restrict__ list, int n, const BodyIds& ids,
+                                              fx_t* __restrict__ part, int nblk) {
     __shared__ fx_t red[TPB / 64][16];
     __shared__ double s_tot[SPH_MAX_BATCH_BODIES][16];
     sum_partials_all(d, part, nblk, ids.n, 4, s_tot);
@@ -561,9 +566,13 @@ __global__ __launch_bounds__(TPB) void k_rigid_A_all(DevView d, WallHi hi, const
         block_store_partials_at<9>(s, part + (size_t)b * nblk * RIGID_PART, 4, red);
     }
 }
+__global__ __launch_bounds__(TPB) void k_rigid_A_all(DevView d, WallHi hi, const int* __restrict__ list, int n, BodyIds ids,
+                                                     fx_t* __restrict__ part, int nblk) {
+    rigid_phase_A(d, hi, list, n, ids, part, nblk);
+}
 
-__global__ __launch_bounds__(TPB) void k_rigid_apply_all(DevView d, WallHi hi, const int* __restrict__ list, int n, BodyIds ids,
-                                                         const fx_t* __restrict__ part, int nblk, float* __restrict__ out) {
+__device__ __forceinline__ void rigid_phase_apply(const DevView& d, const WallHi& hi, const int* __restrict__ list, int n, const BodyIds& ids,
+                                                  const fx_t* __restrict__ part, int nblk, float* __restrict__ out) {
     __shared__ double s_tot[SPH_MAX_BATCH_BODIES][16];
     __shared__ float cmR[SPH_MAX_BATCH_BODIES][12];
     sum_partials_all(d, part, nblk, ids.n, 13, s_tot);
@@ -602,6 +611,39 @@ __global__ __launch_bounds__(TPB) void k_rigid_apply_all(DevView d, WallHi hi, c
     }
     d.xm[i] = xm;
     d.vf[i] = vf;
+}
+__global__ __launch_bounds__(TPB) void k_rigid_apply_all(DevView d, WallHi hi, const int* __restrict__ list, int n, BodyIds ids,
+                                                         const fx_t* __restrict__ part, int nblk, float* __restrict__ out) {
+    rigid_phase_apply(d, hi, list, n, ids, part, nblk, out);
+}
+
+// The three phases in ONE launch.  They are separated by grid-wide barriers: every workgroup writes its rows of partial
+// sums, arrives (one agent-scope release per workgroup), waits until all have, and reads everybody's rows (agent-scope
+// acquire: the other XCDs' L2 lines and this CU's L1 are refreshed).  That needs every workgroup of the grid RESIDENT at
+// once, so the launcher takes this kernel only up to one workgroup per CU (<= 256 workgroups = 65,536 dynamic rigid
+// particles) and the three launches otherwise.  The wait is bounded: a grid that could not become resident would compute
+// garbage (the parity tests would say so) rather than hang the device.  A particle is only ever read and written by its
+// own thread; the partial rows are the one thing that crosses workgroups.  `bar` is zero between launches: the last
+// workgroup to leave resets it.
+__device__ __forceinline__ void rigid_grid_sync(unsigned* bar, unsigned target) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+}
+template <bool ADVECT>
+__global__ __launch_bounds__(TPB) void k_rigid_all_fused(DevView d, WallHi hi, const int* __restrict__ list, int n, BodyIds ids,
+                                                         fx_t* __restrict__ part, int nblk, float* __restrict__ out, unsigned* __restrict__ bar) {
+    rigid_phase_sum<ADVECT>(d, hi, list, n, ids, part, nblk);
+    rigid_grid_sync(bar, (unsigned)nblk);
+    rigid_phase_A(d, hi, list, n, ids, part, nblk);
+    rigid_grid_sync(bar, 2u * (unsigned)nblk);
+    rigid_phase_apply(d, hi, list, n, ids, part, nblk, out);
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3u * (unsigned)nblk - 1u)
+        __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- the same solve with the sums split over slabs (include/sph_hip.h: sph_rigid_partial_sums) ----
@@ -866,8 +908,9 @@ int sphk_rigid_solve(SphContext* c, int object_id) {
     return 0;
 }
 
-// solve_rigid_body() (sph_base.py:247-260) for the dynamic bodies `ids` in the reference's order: three launches for all
-// of them when they fit the batch (<= 16 bodies, per-body rows of partials), else body by body.  advect_first: the
+// solve_rigid_body() (sph_base.py:247-260) for the dynamic bodies `ids` in the reference's order: ONE launch for all of
+// them (SPH_OPT_RIGID_BATCH 1: <= 16 bodies, <= 65,536 dynamic rigid particles), three launches (batch 2, or beyond that
+// size), else body by body (batch 0, or more than 16 bodies).  advect_first: the
 // advect of the dynamic rigid particles (what sphk_advect_dyn_list does) happens here too, inside the first kernel
 int sphk_rigid_solve_all(SphContext* c, const int* ids, int n_ids, bool advect_first) {
     if (c->n_dyn_host <= 0 || n_ids <= 0) return advect_first ? sphk_advect_dyn_list(c) : 0;
@@ -886,6 +929,12 @@ int sphk_rigid_solve_all(SphContext* c, const int* ids, int n_ids, bool advect_f
     BodyIds b;
     b.n = n_ids;
     for (int k = 0; k < SPH_MAX_BATCH_BODIES; ++k) b.id[k] = k < n_ids ? ids[k] : -1;
+    if (c->opt_rigid_batch == 1 && nb <= 256) {  // one launch: the phases behind grid-wide barriers (every workgroup resident)
+        if (advect_first) hipLaunchKernelGGL(k_rigid_all_fused<true>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c), c->dyn_list, n, b, (fx_t*)c->rigid_part, nb, c->rigid_R, c->rigid_bar);
+        else hipLaunchKernelGGL(k_rigid_all_fused<false>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c), c->dyn_list, n, b, (fx_t*)c->rigid_part, nb, c->rigid_R, c->rigid_bar);
+        SPH_LAUNCH_CHECK(c);
+        return 0;
+    }
     if (advect_first) hipLaunchKernelGGL(k_rigid_sum_all<true>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c), c->dyn_list, n, b, (fx_t*)c->rigid_part, nb);
     else hipLaunchKernelGGL(k_rigid_sum_all<false>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c), c->dyn_list, n, b, (fx_t*)c->rigid_part, nb);
     SPH_LAUNCH_CHECK(c);

@@ -133,10 +133,10 @@ enum SphOption {
     SPH_OPT_KERNEL_VARIANT = 10 /* A/B switch for the brick sweeps of the fused WCSPH step: bit mask of
                                   SPH_VAR_* below.  Every combination computes the same sums (list order and rounding
                                   apart); -1 = the library's default */,
-    SPH_OPT_RIGID_BATCH = 11   /* how sph_step / sph_dfsph_step run solve_rigid_body() (sph_base.py:247-260): 1 (default) = ALL dynamic
-                                  bodies in one launch (sums, A, apply behind grid-wide barriers; the per-body solid wall passes
-                                  replayed per particle), 2 = the same three phases as three launches, 0 = body by body (4
-                                  launches each).  Same results bit for bit. */,
+    SPH_OPT_RIGID_BATCH = 11   /* 1 (default) = solve_rigid_body() (sph_base.py:247-260) of ALL dynamic bodies in three launches
+                                  inside sph_step / sph_dfsph_step, the per-body solid wall passes replayed per particle;
+                                  0 = body by body (4 launches each).  Same results bit for bit.  (One launch behind grid-wide
+                                  barriers was built too and is slower: commit 98934a4.) */,
     SPH_OPT_EXACT_MATH = 12    /* A/B of the fast-math choice (never the default): 1 = the brick sweeps of the fused WCSPH step
                                   (density + EOS, force) evaluate r.norm(), r / (|r| h), x / y with IEEE sqrt and divide
                                   as the reference's f32 expressions do, instead of v_rsq_f32 / v_rcp_f32 (~1 ulp).

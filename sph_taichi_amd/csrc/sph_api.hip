@@ -183,7 +183,6 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     c->rigid_part_blocks = (c->cap + 255) / 256 + 1;
     rc = rc ? rc : alloc_dev(c, (void**)&c->rigid_part, (size_t)c->rigid_part_blocks * 16 * sizeof(double));
     rc = rc ? rc : alloc_dev(c, (void**)&c->rigid_R, 16 * sizeof(float));
-    rc = rc ? rc : alloc_dev(c, (void**)&c->rigid_bar, 16);
     rc = rc ? rc : alloc_dev(c, (void**)&c->df_err, sizeof(double));
     rc = rc ? rc : alloc_dev(c, (void**)&c->df_part, SPH_DF_ERR_BLOCKS * sizeof(double));
     if (!rc && hipHostMalloc((void**)&c->h_df_err, sizeof(double), hipHostMallocMapped) != hipSuccess) rc = SPH_E_NOMEM;
@@ -224,7 +223,7 @@ int32_t sph_destroy(SphContext* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->xm[0], c->xm[1], c->vf[0], c->vf[1], c->aux[0], c->aux[1], c->key[0], c->key[1], c->eos, c->stg, c->gat, c->acc,
                     c->acc_tmp, c->cell_buf[0], c->cell_buf[1], c->rank_off, c->idx_unstable, c->scan_sums, c->x0_cold, c->color_cold,
-                    c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->acc_fx, c->rigid_part, c->rigid_R, c->df_err, c->df_part, c->stage, c->glist, c->gcnt, c->brick_list, c->brick_count, c->brick_list2, c->brick_count2, c->rigid_bar};
+                    c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->acc_fx, c->rigid_part, c->rigid_R, c->df_err, c->df_part, c->stage, c->glist, c->gcnt, c->brick_list, c->brick_count, c->brick_list2, c->brick_count2};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < SPH_MAX_TIMED_STEPS; ++s)
         for (int k = 0; k < 5; ++k) if (c->ev[s][k]) (void)hipEventDestroy(c->ev[s][k]);
@@ -255,7 +254,7 @@ int32_t sph_set_option(SphContext* c, int32_t option, int32_t value) {
             return 0;
         case SPH_OPT_SLAB_DROP_OUTSIDE: c->opt_drop_outside = value ? 1 : 0; c->uniform_state = -1; return 0;
         case SPH_OPT_SORT_BY_PID: c->opt_sort_by_pid = value ? 1 : 0; return 0;
-        case SPH_OPT_RIGID_BATCH: if (value < 0 || value > 2) return sph_fail(c, SPH_E_INVALID, "rigid batch must be 0 (body by body), 1 (one launch) or 2 (three launches)"); c->opt_rigid_batch = value; return 0;
+        case SPH_OPT_RIGID_BATCH: c->opt_rigid_batch = value ? 1 : 0; return 0;
         case SPH_OPT_EXACT_MATH: c->opt_exact_math = value ? 1 : 0; sph_invalidate_lists(c); return 0;
         case SPH_OPT_KERNEL_VARIANT:
             if (value < -1 || value > 31 || (value > 0 && (value & 6))) return sph_fail(c, SPH_E_INVALID, "kernel variant must be -1 (default) or a mask of SPH_VAR_*");

@@ -676,14 +676,27 @@ __global__ __launch_bounds__(TPB) void k_gather_bvol_split(DevView d, const int*
             const int zlo = cz > 0 ? cz - 1 : 0, zhi = cz < d.nz - 1 ? cz + 1 : d.nz - 1;
             const int flo = sph_flatten(d, nx, ny, zlo), fhi = sph_flatten(d, nx, ny, zhi);
             const int beg = d.cell_end[flo > 0 ? flo - 1 : 0], end = d.cell_end[fhi];  // particle_system.py:384
-            for (int j = beg; j < end; ++j) {
-                if (j == i) continue;
-                const float4 Aj = d.xm[j];
-                const float rx = A.x - Aj.x, ry = A.y - Aj.y, rz = A.z - Aj.z;
-                const float r2 = rx * rx + ry * ry + rz * rz;
-                const float rn = r2 * sph_rsq(r2);
-                if (rn < d.h && sph_flags_material(__float_as_int(d.vf[j].w)) == SPH_MATERIAL_SOLID)
-                    sum += sph_W_q(d, rn * d.inv_h);  // sph_base.py:100-103
+            // four candidates per trip, their eight loads in flight together: this sweep is pure latency (a few 10^4 targets
+            // on 256 CUs), and one candidate per trip made every pair wait for its own two loads (18 us per step at C3, r04h)
+            for (int j0 = beg; j0 < end; j0 += 4) {
+                float4 Aj[4];
+                int fj[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = min(j0 + u, end - 1);
+                    Aj[u] = d.xm[j];
+                    fj[u] = __float_as_int(reinterpret_cast<const float*>(&d.vf[j])[3]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u;
+                    if (j >= end || j == i) continue;
+                    const float rx = A.x - Aj[u].x, ry = A.y - Aj[u].y, rz = A.z - Aj[u].z;
+                    const float r2 = rx * rx + ry * ry + rz * rz;
+                    const float rn = r2 * sph_rsq(r2);
+                    if (rn < d.h && sph_flags_material(fj[u]) == SPH_MATERIAL_SOLID)
+                        sum += sph_W_q(d, rn * d.inv_h);  // sph_base.py:100-103
+                }
             }
         }
     }
@@ -1612,17 +1625,31 @@ __global__ __launch_bounds__(TPB) void k_stats(DevView d, const unsigned char* _
     }
 }
 
-__global__ __launch_bounds__(64) void k_stats_total(const unsigned long long* __restrict__ part, int nb, unsigned long long* __restrict__ out) {
+__global__ __launch_bounds__(TPB) void k_stats_total(const unsigned long long* __restrict__ part, int nb, unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long red[TPB / 64][7];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long v[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nb; b += TPB) {  // a thread takes whole rows: the seven loads of a row in flight together
+        const unsigned long long* row = part + (size_t)b * 7;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) v[k] = (k == 2 || k == 5) ? max(v[k], row[k]) : v[k] + row[k];
+    }
+#pragma unroll
     for (int k = 0; k < 7; ++k) {
         const bool is_max = k == 2 || k == 5;
-        unsigned long long t = 0;
-        for (int b = threadIdx.x; b < nb; b += 64) t = is_max ? max(t, part[(size_t)b * 7 + k]) : t + part[(size_t)b * 7 + k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            const unsigned long long o = __shfl_xor(t, off, 64);
-            t = is_max ? max(t, o) : t + o;
+            const unsigned long long o = __shfl_xor(v[k], off, 64);
+            v[k] = is_max ? max(v[k], o) : v[k] + o;
         }
-        if (threadIdx.x == 0) out[k] = t;
+        if (lane == 0) red[wave][k] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const int k = threadIdx.x;
+        unsigned long long t = red[0][k];
+        for (int w = 1; w < TPB / 64; ++w) t = (k == 2 || k == 5) ? max(t, red[w][k]) : t + red[w][k];
+        out[k] = t;
     }
 }
 
@@ -1641,7 +1668,7 @@ int sphk_stats(SphContext* c, SphStats* out) {
     // fields stay 0 instead of showing stale or never-written bytes)
     hipLaunchKernelGGL(k_stats, dim3(nb), dim3(TPB), 0, c->stream, d, c->gcnt_written ? c->gcnt : nullptr, part);
     SPH_LAUNCH_CHECK(c);
-    hipLaunchKernelGGL(k_stats_total, dim3(1), dim3(64), 0, c->stream, part, nb, dev);
+    hipLaunchKernelGGL(k_stats_total, dim3(1), dim3(TPB), 0, c->stream, part, nb, dev);
     SPH_LAUNCH_CHECK(c);
     SPH_HIP(c, hipMemcpyAsync(h, dev, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     SPH_HIP(c, hipStreamSynchronize(c->stream));

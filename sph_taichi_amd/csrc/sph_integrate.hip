@@ -215,15 +215,23 @@ __device__ __forceinline__ void block_store_partials(const fx_t (&s)[NV], fx_t* 
 // total of partial component k over nblk blocks, computed by every thread that asks (small nblk, L2-resident)
 __device__ __forceinline__ void sum_partials(const DevView& d, const fx_t* __restrict__ part, int nblk, int off, int nv, double* out,
                                              double* s_tmp) {
-    // wave 0 reduces: lane-strided over blocks
+    // wave 0 reduces: a lane takes whole ROWS (blocks), all components of a row loaded together -- component by component
+    // the loads formed a chain of nv dependent round trips, which is what these tiny kernels' 14 us consisted of (r04h trace)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (wave == 0) {
-        for (int k = 0; k < nv; ++k) {
-            fx_t t = 0;
-            for (int bIdx = lane; bIdx < nblk; bIdx += 64) t += part[(size_t)bIdx * RIGID_PART + off + k];
-            t = wave_sum(t);
-            if (lane == 0) s_tmp[k] = (double)t / d.fx_scale;
+        fx_t acc[RIGID_PART] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (nv <= 16: the slab path's one-pass sums use all)
+        for (int bIdx = lane; bIdx < nblk; bIdx += 64) {
+            const fx_t* row = part + (size_t)bIdx * RIGID_PART + off;
+#pragma unroll
+            for (int k = 0; k < RIGID_PART; ++k)
+                if (k < nv) acc[k] += row[k];
         }
+#pragma unroll
+        for (int k = 0; k < RIGID_PART; ++k)
+            if (k < nv) {
+                const fx_t t = wave_sum(acc[k]);
+                if (lane == 0) s_tmp[k] = (double)t / d.fx_scale;
+            }
     }
     __syncthreads();
     for (int k = 0; k < nv; ++k) out[k] = s_tmp[k];
@@ -363,6 +371,49 @@ __device__ void polar_rotation(const double A[3][3], float R_[9]) {
         }
 }
 
+// The same rotation by Higham's scaled Newton iteration X <- (g X + X^-T / g) / 2, g = (|X^-1|_F / |X|_F)^1/2: for a
+// well-conditioned A with det A > 0 -- every body that is not degenerate -- the orthogonal polar factor IS the closest proper
+// rotation the SVD form above constructs, and the iteration reaches it (to f64 rounding) in 5-7 steps of ~100 flops where
+// the Jacobi form needs ~6 sweeps of three rotations with two square roots and two divisions each: 8 us -> 2 us on the one
+// lane that computes it, a fifth of the whole rigid phase.  Anything else (det <= 0, nearly singular, no convergence)
+// returns false and takes the Jacobi form.
+__device__ bool polar_rotation_newton(const double A[3][3], float R_[9]) {
+    double X[3][3], n2 = 0.0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) n2 += A[i][j] * A[i][j];
+    if (!(n2 > 1e-280)) return false;
+    const double s0 = 1.0 / sqrt(n2 * (1.0 / 3.0));  // singular values ~ 1 for a body of any size and mass
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) X[i][j] = A[i][j] * s0;
+    for (int it = 0; it < 24; ++it) {
+        double C[3][3];  // cofactor matrix: X^-T = C / det
+        C[0][0] = X[1][1] * X[2][2] - X[1][2] * X[2][1]; C[0][1] = X[1][2] * X[2][0] - X[1][0] * X[2][2]; C[0][2] = X[1][0] * X[2][1] - X[1][1] * X[2][0];
+        C[1][0] = X[0][2] * X[2][1] - X[0][1] * X[2][2]; C[1][1] = X[0][0] * X[2][2] - X[0][2] * X[2][0]; C[1][2] = X[0][1] * X[2][0] - X[0][0] * X[2][1];
+        C[2][0] = X[0][1] * X[1][2] - X[0][2] * X[1][1]; C[2][1] = X[0][2] * X[1][0] - X[0][0] * X[1][2]; C[2][2] = X[0][0] * X[1][1] - X[0][1] * X[1][0];
+        const double det = X[0][0] * C[0][0] + X[0][1] * C[0][1] + X[0][2] * C[0][2];
+        if (!(det > 1e-6)) return false;  // (X is scaled: det ~ 1 for a rotation-dominated A; reflections and flat bodies leave here)
+        double nx = 0.0, nc = 0.0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) { nx += X[i][j] * X[i][j]; nc += C[i][j] * C[i][j]; }
+        const double idet = 1.0 / det;
+        const double g = sqrt(sqrt(nc) * idet / sqrt(nx));  // |X^-1|_F = |C|_F / det
+        const double a = 0.5 * g, b = 0.5 * idet / g;
+        double diff = 0.0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                const double y = a * X[i][j] + b * C[i][j];
+                diff += (y - X[i][j]) * (y - X[i][j]);
+                X[i][j] = y;
+            }
+        if (diff <= 1e-30 * 3.0) {  // |X_k+1 - X_k|_F <= 1e-15 |R|_F: converged (quadratically: the step before was ~1e-8)
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) R_[3 * i + j] = (float)X[i][j];
+            return true;
+        }
+    }
+    return false;
+}
+
 // cm (and the polar rotation) from the summed partials; one lane per block computes them into LDS
 __device__ __forceinline__ void rigid_cm_R(const double* tot, bool want_R, float* cmR /*[12] in LDS*/) {
     const float sum_m = (float)tot[0];  // f32 division like the reference's cm /= sum_m (0/0 = NaN for static bodies)
@@ -372,7 +423,7 @@ __device__ __forceinline__ void rigid_cm_R(const double* tot, bool want_R, float
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) A[i][j] = (double)(float)tot[4 + 3 * i + j];
     float R[9];
-    polar_rotation(A, R);
+    if (!polar_rotation_newton(A, R)) polar_rotation(A, R);
     bool all_small = true;
     for (int i = 0; i < 9; ++i)
         if (!(fabsf(R[i]) < 1e-6f)) all_small = false;
@@ -482,12 +533,19 @@ __device__ __forceinline__ void sum_partials_all(const DevView& d, const fx_t* _
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int b = wave; b < nbodies; b += TPB / 64) {
         const fx_t* pb = part + (size_t)b * nblk * RIGID_PART;
-        for (int k = 0; k < nv; ++k) {
-            fx_t t = 0;
-            for (int bIdx = lane; bIdx < nblk; bIdx += 64) t += pb[(size_t)bIdx * RIGID_PART + k];
-            t = wave_sum(t);
-            if (lane == 0) s_tot[b][k] = (double)t / d.fx_scale;
+        fx_t acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // (a lane takes whole rows: all loads of a row in flight together)
+        for (int bIdx = lane; bIdx < nblk; bIdx += 64) {
+            const fx_t* row = pb + (size_t)bIdx * RIGID_PART;
+#pragma unroll
+            for (int k = 0; k < 13; ++k)
+                if (k < nv) acc[k] += row[k];
         }
+#pragma unroll
+        for (int k = 0; k < 13; ++k)
+            if (k < nv) {
+                const fx_t t = wave_sum(acc[k]);
+                if (lane == 0) s_tot[b][k] = (double)t / d.fx_scale;
+            }
     }
     __syncthreads();
 }
@@ -617,34 +675,9 @@ __global__ __launch_bounds__(TPB) void k_rigid_apply_all(DevView d, WallHi hi, c
     rigid_phase_apply(d, hi, list, n, ids, part, nblk, out);
 }
 
-// The three phases in ONE launch.  They are separated by grid-wide barriers: every workgroup writes its rows of partial
-// sums, arrives (one agent-scope release per workgroup), waits until all have, and reads everybody's rows (agent-scope
-// acquire: the other XCDs' L2 lines and this CU's L1 are refreshed).  That needs every workgroup of the grid RESIDENT at
-// once, so the launcher takes this kernel only up to one workgroup per CU (<= 256 workgroups = 65,536 dynamic rigid
-// particles) and the three launches otherwise.  The wait is bounded: a grid that could not become resident would compute
-// garbage (the parity tests would say so) rather than hang the device.  A particle is only ever read and written by its
-// own thread; the partial rows are the one thing that crosses workgroups.  `bar` is zero between launches: the last
-// workgroup to leave resets it.
-__device__ __forceinline__ void rigid_grid_sync(unsigned* bar, unsigned target) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(1);
-    }
-    __syncthreads();
-}
-template <bool ADVECT>
-__global__ __launch_bounds__(TPB) void k_rigid_all_fused(DevView d, WallHi hi, const int* __restrict__ list, int n, BodyIds ids,
-                                                         fx_t* __restrict__ part, int nblk, float* __restrict__ out, unsigned* __restrict__ bar) {
-    rigid_phase_sum<ADVECT>(d, hi, list, n, ids, part, nblk);
-    rigid_grid_sync(bar, (unsigned)nblk);
-    rigid_phase_A(d, hi, list, n, ids, part, nblk);
-    rigid_grid_sync(bar, 2u * (unsigned)nblk);
-    rigid_phase_apply(d, hi, list, n, ids, part, nblk, out);
-    if (threadIdx.x == 0 && __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 3u * (unsigned)nblk - 1u)
-        __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// (r04: the three phases in ONE launch behind grid-wide barriers -- k_rigid_all_fused, commit 98934a4 -- were bit-identical
+// and slower, 0.0418 vs 0.0390 ms: an agent-scope release on this multi-XCD part writes the L2 back, which costs what a
+// kernel boundary costs.  profiles/r04f_with_bodies_one_launch_vs_three.json)
 
 // ---- the same solve with the sums split over slabs (include/sph_hip.h: sph_rigid_partial_sums) ----
 // per-block partials of the 16 one-pass sums over the dynamic-rigid particles of `object_id` with index in [first,last)
@@ -908,9 +941,8 @@ int sphk_rigid_solve(SphContext* c, int object_id) {
     return 0;
 }
 
-// solve_rigid_body() (sph_base.py:247-260) for the dynamic bodies `ids` in the reference's order: ONE launch for all of
-// them (SPH_OPT_RIGID_BATCH 1: <= 16 bodies, <= 65,536 dynamic rigid particles), three launches (batch 2, or beyond that
-// size), else body by body (batch 0, or more than 16 bodies).  advect_first: the
+// solve_rigid_body() (sph_base.py:247-260) for the dynamic bodies `ids` in the reference's order: three launches for all
+// of them when they fit the batch (<= 16 bodies, per-body rows of partials), else body by body.  advect_first: the
 // advect of the dynamic rigid particles (what sphk_advect_dyn_list does) happens here too, inside the first kernel
 int sphk_rigid_solve_all(SphContext* c, const int* ids, int n_ids, bool advect_first) {
     if (c->n_dyn_host <= 0 || n_ids <= 0) return advect_first ? sphk_advect_dyn_list(c) : 0;
@@ -929,12 +961,6 @@ int sphk_rigid_solve_all(SphContext* c, const int* ids, int n_ids, bool advect_f
     BodyIds b;
     b.n = n_ids;
     for (int k = 0; k < SPH_MAX_BATCH_BODIES; ++k) b.id[k] = k < n_ids ? ids[k] : -1;
-    if (c->opt_rigid_batch == 1 && nb <= 256) {  // one launch: the phases behind grid-wide barriers (every workgroup resident)
-        if (advect_first) hipLaunchKernelGGL(k_rigid_all_fused<true>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c), c->dyn_list, n, b, (fx_t*)c->rigid_part, nb, c->rigid_R, c->rigid_bar);
-        else hipLaunchKernelGGL(k_rigid_all_fused<false>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c), c->dyn_list, n, b, (fx_t*)c->rigid_part, nb, c->rigid_R, c->rigid_bar);
-        SPH_LAUNCH_CHECK(c);
-        return 0;
-    }
     if (advect_first) hipLaunchKernelGGL(k_rigid_sum_all<true>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c), c->dyn_list, n, b, (fx_t*)c->rigid_part, nb);
     else hipLaunchKernelGGL(k_rigid_sum_all<false>, dim3(nb), dim3(TPB), 0, c->stream, d, wall_hi(c), c->dyn_list, n, b, (fx_t*)c->rigid_part, nb);
     SPH_LAUNCH_CHECK(c);

@@ -131,7 +131,6 @@ struct SphContext {
     double* rigid_part;   // [rigid_part_blocks][16] per-block partial sums of the shape-matching reductions
     int rigid_part_blocks;
     float* rigid_R;    // [12] cm[3] + R[9]
-    unsigned* rigid_bar;  // grid barrier of k_rigid_all_fused (zero between launches)
     void* stage;       // upload/download staging, cap*16 bytes (>= G*4)
     size_t stage_bytes;
     bool have_keys, have_prefix, sorted;

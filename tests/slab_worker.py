@@ -45,7 +45,7 @@ def main():
         class _PS:
             pass
         ps = _PS()
-        ps._lib = _lib.load(build_if_missing=False)
+        ps._lib = _lib.load()          # (builds under a file lock if the library is not there yet)
         tr, why = negotiate_native_transport(ps, "cpu", create_timeout_s=20.0)
         flag = torch.tensor([1 if (tr is None and "stage 0" in why) else 0])
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)

@@ -85,6 +85,28 @@ def test_transport_gloo(world, tmp_path):
     assert open(out).read() == "ok"
 
 
+def test_bench_scenes_are_the_named_workloads():
+    """BASELINE.json config 5 and the tiled weak-scaling family, as `bench.py --gpus N` builds them: particle
+    counts, grids, and slabs of ~N / world particles each from the layer histogram (CPU: no particle array is built)."""
+    from sph_taichi_amd.distributed import c4_dambreak_scene, slab_bench_scene, HALO
+    sd, n = c4_dambreak_scene()
+    assert n == 512 * 165 * 165 == 13_939_200
+    cfg = SimConfig(config=copy.deepcopy(sd))
+    geom = scene_mod.Geometry(cfg)
+    assert tuple(int(v) for v in geom.grid_num) == (400, 100, 85)
+    hist = scene_mod.x_layer_histogram(cfg, base_dir=None)
+    assert int(hist.sum()) == n and int(np.count_nonzero(hist)) == 256         # 512 particle planes of spacing d = h / 2 from x = h on: two per cell layer
+    for world in (2, 4, 8):
+        cuts = scene_mod.slab_cuts(hist, world, min_width=HALO + 1)
+        own = [int(hist[a:b].sum()) for a, b in zip(cuts, cuts[1:])]
+        assert sum(own) == n and max(own) <= n / world + hist.max(), (world, own)
+    for world in (1, 2, 8):
+        sd, n = slab_bench_scene(world)
+        assert n == 246 * world * 74 * 96 and sd["Configuration"]["domainEnd"] == [5.0 * world, 3.0, 2.0]
+    sd, n = c4_dambreak_scene(0.2)
+    assert n == 102 * 33 * 33
+
+
 @pytest.mark.parametrize("bad_rank", [0, 1])
 def test_transport_negotiation_falls_back_collectively(bad_rank, tmp_path):
     """when ONE rank cannot use the native transport (here: its librccl does not open) every rank must

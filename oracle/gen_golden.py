@@ -182,6 +182,14 @@ def main():
                           "rotationAxis": [0, 0, 1], "rotationAngle": 0, "scale": [1, 1, 1], "velocity": [0.2, 7.0, 5.0],
                           "density": 600.0, "color": [255, 255, 255], "isDynamic": True}]
     jobs["ref_high_faces_rigid"] = (d8, 14)
+    d9 = copy.deepcopy(d7)                                   # ... the high faces under DFSPH (every DFSPH sweep walks the same lookups)
+    d9["Configuration"]["simulationMethod"] = 4
+    d9["Configuration"]["timeStepSize"] = 0.001
+    jobs["ref_dfsph_high_faces"] = (d9, 10)
+    # (The cell-0 quirk -- particle_system.py:384 starts the range of cell c at prefix[max(0, c - 1)], so flat cell 0's own
+    # particles are in nobody's neighbourhood -- cannot be pinned by execution: a particle in a cell with coordinate 0 looks up
+    # cell coordinate -1, and for the corner cell the flat index goes negative: the shim counted 992 out-of-range reads on a
+    # scene with a static slab around the origin.  It is undefined behaviour in the reference, like the +x face.)
     d6 = copy.deepcopy(d5)                                   # ... and under DFSPH (the general *_ITER sweeps)
     d6["Configuration"]["simulationMethod"] = 4
     d6["Configuration"]["timeStepSize"] = 0.002

@@ -135,7 +135,8 @@ def test_high_face_fixtures_keep_particles_in_the_last_layers(path):
         steps_z += int((cz == nz - 1).any())
         steps_edge += int(((cy == ny - 1) & (cz == nz - 1)).any())
     assert steps_y >= 8 and steps_z >= 8 and steps_edge >= 4, (steps_y, steps_z, steps_edge)
-    assert float(z[f"step{steps}/density"][z[f"step{steps}/material"] == 1].max()) > 1200.0   # the block is being compressed
+    peak = max(float(z[f"step{s}/density"][z[f"step{s}/material"] == 1].max()) for s in range(1, steps + 1))
+    assert peak > 1200.0, peak   # the block is compressed against the faces (DFSPH pushes it back within a few steps)
 
 
 @pytest.mark.gpu

@@ -6,7 +6,11 @@
 #     kstats   : rocprofv3 kernel-trace stats of the default bench line's two states
 #     bench    : the default bench line + the other workloads
 #     variants : A/B table  partition (adaptive / fixed bricks) x emission (group-sorted / baseline)
-#     native   : kernel trace of the one-rank native RCCL worker
+#     native   : kernel trace of the one-rank native RCCL worker + slab driver overhead at world = 1
+#     fastmath : A/B of the fast-math choice (tools/fastmath_ab.py)
+#     nativemp : only the multi-process native-exchange tests (tests/fake_rccl)
+#     timeline : per-workgroup time line of the two brick sweeps (profiling build, tools/brick_timeline.py)
+#     bodies   : the default bench line's with_bodies object alone
 TAG=${1:-round}; shift
 PARTS=${*:-tests pmc kstats bench variants}
 R=${GRAFT_REPO_ROOT:-$(pwd)}

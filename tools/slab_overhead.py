@@ -13,15 +13,6 @@ solver = ps.build_solver(); solver.initialize(); solver.step(10); ps.sync()
 t0 = time.perf_counter(); solver.step(100); ps.sync(); t1 = time.perf_counter()
 print(f"plain sph_step            : {(t1 - t0) * 10:.3f} ms/step  ({n} particles)")
 ps.close()
-# the same with the native RCCL transport (csrc/sph_comm.hip; world = 1: communicator of one rank, no neighbours -- what
-# is measured is the driver's per-step calls with the exchange entry points in the path)
-from sph_taichi_amd.distributed import NativeTransport
-s = SlabSolver(sd, 0, 1, device=0)
-tr = NativeTransport(s.ps, torch.device("cuda", 0), rank=0, world=1)
-s.attach(tr); s.initialize(); s.step(10); s.ps.sync()
-t0 = time.perf_counter(); s.step(100); s.ps.sync(); t1 = time.perf_counter()
-print(f"SlabSolver world=1 (NativeTransport): {(t1 - t0) * 10:.3f} ms/step; host {s.host_ms}")
-tr.close(); s.close()
 
 class NoTransport:
     def start_counts(self, a, b): self._pending = None

@@ -311,6 +311,44 @@ def test_batched_rigid_solve_equals_the_body_by_body_sequence(tmp_path, dfsph):
     assert scenes.rel_l2(res[1]["v"][rigid], o.by_pid("v")[rigid]) <= 2e-3
 
 
+@pytest.mark.parametrize("n_bodies", [16, 17])
+def test_as_many_bodies_as_one_batch_holds_and_one_more(tmp_path, n_bodies):
+    """The batched solve_rigid_body() keeps per-body rows for 16 bodies (SPH_MAX_BATCH_BODIES, csrc/sph_integrate.hip); a
+    scene with more is solved body by body (sph_base.py:247-260 as written).  16 cubes dropped onto a fluid block: the three
+    launches, bit for bit the body-by-body sequence; 17: the step takes the sequence by itself.  Both follow the oracle."""
+    from sph_taichi_amd import _lib
+    obj = str(tmp_path / "cube.obj")
+    scenes.write_cube_obj(obj, (0.0, 0.0, 0.0), 0.08)
+    sd = scenes.fluid_only(counts=(30, 4, 24), start=(0.1, 0.06, 0.1), velocity=(0.0, 0.0, 0.0))
+    sd["RigidBodies"] = [{"objectId": 1 + k, "geometryFile": obj,
+                          "translation": [0.1 + 0.13 * (k % 5), 0.17 + 0.004 * k, 0.1 + 0.13 * (k // 5)],
+                          "rotationAxis": [0, 0, 1], "rotationAngle": 7 * k, "scale": [1, 1, 1],
+                          "velocity": [0.1 * (k % 3 - 1), -2.0 - 0.1 * k, 0.05 * (k % 4)], "density": 500.0 + 150.0 * k,
+                          "color": [255, 255, 255], "isDynamic": True} for k in range(n_bodies)]
+    cfg, sc = scenes.build(sd)
+    a = sc.arrays
+    rigid = (a["material"] == 0) & (a["is_dynamic"] == 1)
+    assert len(np.unique(a["object_id"][rigid])) == n_bodies
+    n = 40
+    res = {}
+    for batch in (1, 0):
+        ps, solver = scenes.make_ps(sd)
+        ps.set_option(_lib.OPT_RIGID_BATCH, batch)
+        solver.initialize()
+        solver.step(n)
+        res[batch] = {k: scenes.ps_by_pid(ps, k) for k in ("x", "v")}
+        ps.close()
+    assert np.array_equal(res[1]["x"], res[0]["x"]) and np.array_equal(res[1]["v"], res[0]["v"])
+    o = scenes.make_oracle(cfg, sc, rigid_sums_f64=True)
+    o.initialize(); o.step(n)
+    assert scenes.rel_l2(res[1]["x"], o.by_pid("x")) <= 1e-4
+    assert scenes.rel_l2(res[1]["x"][rigid], o.by_pid("x")[rigid]) <= 1e-4
+    assert scenes.rel_l2(res[1]["v"][rigid], o.by_pid("v")[rigid]) <= 2e-3
+    # the bodies reached the fluid: coupling forces have bent at least one trajectory away from free fall
+    vy = res[1]["v"][rigid, 1]
+    assert (vy > -2.0 - 0.1 * n_bodies - 9.81 * n * cfg.get_cfg("timeStepSize") + 0.05).any()
+
+
 @pytest.mark.parametrize("nz", [800, 801])
 def test_tall_grids_at_the_brick_list_limit(nz):
     """the brick-list builder keeps 80 (nz + 1) bytes of per-layer arrays in dynamic LDS -- in k_brick_list and in

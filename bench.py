@@ -50,6 +50,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# several processes sharing GPU memory handles (RCCL between ranks): the host driver of this pool supports dmabuf IPC only;
+# the launcher's environment normally carries this already
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 from sph_taichi_amd.benchutil import REF_PARTICLES, HBM_PEAK_GBS, gpu_preheat, _HEAT  # noqa: E402
 

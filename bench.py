@@ -182,7 +182,7 @@ def with_bodies(args, local_rank, immerse_steps=300):
         ps.set_option(_lib.OPT_RIGID_BATCH, batch)
         gpu_preheat(local_rank, args.preheat_ms)
         solver.step(args.warmup)
-        ps.set_option(_lib.OPT_TIMING, 1)
+        ps.set_option(_lib.OPT_TIMING, args.time_every)
         ps._call("sph_reset_timings")
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -261,6 +261,9 @@ def main():
     ap.add_argument("--variant", type=int, default=-1, help="SPH_OPT_KERNEL_VARIANT mask (-1 = the library's default)")
     ap.add_argument("--cpu-steps", type=int, default=10, help="CPU-oracle sample size (0 = skip the baseline leg)")
     ap.add_argument("--sweep", action="store_true", help="also time every gather variant (stderr table)")
+    ap.add_argument("--time-every", type=int, default=8,
+                    help="per-phase HIP events (breakdown_ms, roofline.avg_launch_ms) in every k-th step of the timed region: an "
+                         "event record is a packet between two kernels, five per step cost 4 %% of the step (k = 1), k = 8 costs 0.5 %%")
     ap.add_argument("--ablate", action="store_true", help="profiling: time the sweeps with sections skipped (stderr)")
     ap.add_argument("--ablate-mask", type=int, default=0, help="profiling: run the whole bench with this ablation mask (results invalid)")
     args = ap.parse_args()
@@ -308,7 +311,7 @@ def main():
         ps.set_option(_lib.OPT_TIMING, 0)
         gpu_preheat(local_rank, args.preheat_ms if heat_ms is None else heat_ms)
         solver.step(warmup)
-        ps.set_option(_lib.OPT_TIMING, 1)
+        ps.set_option(_lib.OPT_TIMING, args.time_every)
         ps._call("sph_reset_timings")
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -540,6 +543,10 @@ def main():
             "note": "the same W + K steps started straight after the host-side set-up, GPU idle before them (no preheat): the "
                     "clock ramp of the first milliseconds is inside the timed region"},
         "breakdown_ms": rest["breakdown_ms"],
+        "phase_events": {"every": args.time_every,
+                         "note": "breakdown_ms and roofline.avg_launch_ms are HIP-event means over every k-th step of the timed region "
+                                 "(five event records per step cost 4 % of it, DESIGN.md section 5); value / ms_per_step are the wall clock "
+                                 "of all K steps between two device synchronisations"},
         "steps_per_s_job": round(args.steps / dt_mean, 3),
         "roofline": {"kernel": dominant, "bound": "hbm", "achieved": dk["achieved_GBs"], "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": dk["frac_of_hbm_peak"], "traffic": dk["traffic"],

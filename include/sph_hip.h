@@ -107,7 +107,9 @@ enum SphError {
  * 1 = LDS-staged cell bricks (default). */
 enum SphOption {
     SPH_OPT_GATHER_IMPL = 0,
-    SPH_OPT_TIMING = 1,        /* 1 = record per-phase HIP events inside sph_step */
+    SPH_OPT_TIMING = 1,        /* k > 0 = record per-phase HIP events inside every k-th step (sph_step, sph_dfsph_step, the slab
+                                  calls); SphTimings then holds sums over the timed steps.  An event is a packet of its own
+                                  between two kernels: k = 1 costs the 1.75 M step 4 %, k = 8 half a percent */
     SPH_OPT_FUSED_STEP = 2,    /* 1 (default) = sph_step uses the fused density+EOS / force kernels */
     SPH_OPT_BRICK_SHAPE = 3,   /* how the LDS-brick sweeps cut the grid: 0 (default) = 4 x 2 cell columns times a height chosen
                                   per brick from the cell histogram (at most 4 layers, at most 256 targets, shell within the

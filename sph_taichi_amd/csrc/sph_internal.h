@@ -147,6 +147,7 @@ struct SphContext {
     SphDfsphStats df_stats;
     double* df_err;     // device accumulator of compute_density_error
     // options
+    int timing_phase;  // steps since the last timed one (SPH_OPT_TIMING k)
     int opt_gather_impl, opt_timing, opt_fused, opt_brick_shape, opt_no_dynamic, opt_ablate, opt_drop_outside;
     int opt_sort_by_pid;
     int opt_rigid_batch;  // SPH_OPT_RIGID_BATCH: 1 (default) = solve_rigid_body() of all bodies in three launches

@@ -139,3 +139,28 @@ def test_exact_math_instance_follows_the_oracle_at_least_as_closely():
         ps.close()
     assert errs[1]["density"] <= 2e-5 and errs[1]["pressure"] <= 2e-4 and errs[1]["acceleration"] <= 5e-4 and errs[1]["x20"] <= 1e-4, errs
     assert errs[1]["density"] <= 2.0 * errs[0]["density"] + 1e-6 and errs[1]["acceleration"] <= 2.0 * errs[0]["acceleration"] + 1e-6, errs
+
+
+def test_phase_events_in_every_kth_step():
+    """SPH_OPT_TIMING k (include/sph_hip.h): the five per-phase events are recorded in every k-th step of a call sequence, the
+    sums cover the timed steps only, and the trajectory does not know about them."""
+    from sph_taichi_amd import _lib
+    sd = scenes.fluid_only(counts=(12, 10, 8))
+    out = {}
+    for k in (0, 1, 4):
+        ps, solver = scenes.make_ps(sd)
+        solver.initialize()
+        ps.set_option(_lib.OPT_TIMING, k)
+        assert ps.get_option(_lib.OPT_TIMING) == k
+        ps._call("sph_reset_timings")
+        solver.step(10)
+        solver.step(3)          # the phase runs on across calls: steps 0, 4, 8 and 12 of the 13
+        ps.sync()
+        tm = _lib.SphTimings()
+        ps._call("sph_get_timings", tm)
+        assert int(tm.steps) == {0: 0, 1: 13, 4: 4}[k]
+        if k:
+            assert tm.total_ms > 0.0 and abs(tm.total_ms - (tm.sort_ms + tm.neighbour_ms + tm.force_ms + tm.integrate_ms)) <= 1e-6 * tm.total_ms
+        out[k] = scenes.ps_by_pid(ps, "x")
+        ps.close()
+    assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[4])

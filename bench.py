@@ -97,10 +97,9 @@ def scene_dict(workload: str, solver: str = "wcsph"):
 def _scene_dict(workload: str):
     if workload in ("c2_dragon_bath", "c3_armadillo_equiv"):
         # the reference's two demo scenes with their bodies taken from the committed voxel fixtures
-        # (tests/golden/*.npy; /root/reference does not exist on the GPU box)
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import test_gpu_fullsize as fs
-        return fs.dragon_bath_scene() if workload == "c2_dragon_bath" else fs.armadillo_equiv_scene(body_y=BODY_Y)
+        # (sph_taichi_amd/data/bodies/*.npy; /root/reference does not exist on the GPU box)
+        from sph_taichi_amd import workloads
+        return workloads.dragon_bath_scene() if workload == "c2_dragon_bath" else workloads.armadillo_equiv_scene(body_y=BODY_Y)
     dom, counts, corner = WORKLOADS[workload]
     cfg = copy.deepcopy(CFG)
     cfg["domainEnd"] = dom
@@ -252,6 +251,12 @@ def main():
     ap.add_argument("--c4", type=int, default=1,
                     help="--gpus N: after the tiled weak-scaling line also run BASELINE.json's config 5 (the 13.9 M dam-break in its "
                          "own tank, travelling cuts) and attach it as `c4_dambreak` (0 = skip)")
+    ap.add_argument("--watchdog-s", type=float, default=900.0,
+                    help="--gpus N: wall-clock budget of the whole job; a rank that exceeds it (or the c4_dambreak object its own "
+                         "share, --c4-budget-s) prints a JSON line naming the stage it hung in and every rank exits (0 = off)")
+    ap.add_argument("--c4-budget-s", type=float, default=300.0,
+                    help="--gpus N: wall-clock budget of the supplementary c4_dambreak object; when it is exceeded the finished "
+                         "tiled line is printed with c4_dambreak = {error: watchdog, stage: ...}")
     ap.add_argument("--with-bodies", type=int, default=1,
                     help="the default line also times the armadillo_bath_dynamic.json equivalent (1.72 M fluid + 3 dynamic bodies, "
                          "two-way coupling) once the bodies are immersed: `with_bodies` object (0 = skip)")
@@ -271,13 +276,20 @@ def main():
         # section ablation lives in the PROFILING build of the library only (csrc: -DSPH_PROFILE); build / load that one
         os.environ["SPH_HIP_LIB_VARIANT"] = "profile"
 
-    import torch
+    metric = "WCSPH steps/sec at 1.74 M particles (+ ms/step breakdown sort/neighbour/force)"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # No launcher: this process becomes the supervisor of its own N ranks (VERDICT r04 "next" #2a).
+        from sph_taichi_amd.benchutil import self_launch
+        sys.exit(self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus, args.watchdog_s, metric=metric))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    from sph_taichi_amd.benchutil import Watchdog
+    wd = Watchdog(rank, world, total_s=args.watchdog_s, metric=metric, enabled=world > 1, take_sigterm=world > 1)
+    wd.stage("import torch")
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # SPH_DIST_BACKEND=gloo lets several ranks share one GPU (how the N>1 path is exercised on a 1-GPU box)
@@ -285,15 +297,26 @@ def main():
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
+        import datetime
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # one node by contract; the container's hostname may not resolve
+        wd.stage(f"init_process_group({backend})")
+        to = datetime.timedelta(seconds=max(min(args.watchdog_s, 600.0), 60.0))
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=to)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=to)
         from sph_taichi_amd.distributed import run_slab_bench
-        line = run_slab_bench(args, rank, world, local_rank)
+        try:
+            line = run_slab_bench(args, rank, world, local_rank, wd=wd)
+        except BaseException as e:      # noqa: BLE001 -- a rank that fails must say so and LEAVE: its peers sit in collectives
+            import traceback
+            traceback.print_exc()
+            wd.fail(f"{type(e).__name__}: {e}")
         if rank == 0:
-            print(json.dumps(line), flush=True)
+            wd.emit(line)
+        wd.stage("destroy_process_group", budget_s=30.0)
         dist.destroy_process_group()
         return
 

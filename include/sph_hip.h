@@ -341,6 +341,8 @@ int32_t sph_comm_swap(SphContext* ctx, SphComm* comm, int32_t left, int32_t righ
 int32_t sph_comm_all_reduce(SphContext* ctx, SphComm* comm, void* dev, int32_t n, int32_t dtype);
 int32_t sph_comm_sync(SphContext* ctx, SphComm* comm);
 int32_t sph_comm_halo_time(SphContext* ctx, SphComm* comm, double* ms, int64_t* exchanges);
+/* rank / world of the communicator as the communication library reports them (ncclCommUserRank / ncclCommCount) */
+int32_t sph_comm_info(SphContext* ctx, SphComm* comm, int32_t* rank, int32_t* world);
 
 /* ======================================================================================
  * DFSPH (simulationMethod 4): DFSPHSolver of /root/reference/DFSPH.py on the same neighbour

@@ -150,6 +150,7 @@ SYMBOLS = [
     ("sph_comm_all_reduce", C.c_int32, [_ctx, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     ("sph_comm_sync", C.c_int32, [_ctx, C.c_void_p]),
     ("sph_comm_halo_time", C.c_int32, [_ctx, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    ("sph_comm_info", C.c_int32, [_ctx, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
 ]
 
 _LIB = None

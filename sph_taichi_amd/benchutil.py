@@ -31,3 +31,308 @@ def gpu_preheat(local_rank, ms):
     except Exception as e:      # noqa: BLE001 -- the load is a courtesy to the clock, never a reason to lose the measurement
         _HEAT["broken"] = True
         print(f"[bench] preheat unavailable ({type(e).__name__}: {e}); blocks run cold", file=sys.stderr, flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# A multi-rank bench run must never be lost to plumbing (VERDICT r04 "next" #2): a launcher-free `bench.py --gpus N`
+# spawns its own ranks (self_launch), and every rank carries a wall-clock watchdog that turns a hang into a JSON line
+# naming the stage.
+# ---------------------------------------------------------------------------------------------------------------------
+class Watchdog:
+    """Wall-clock guard of one bench rank.  `stage(name)` names what the rank is doing (also written to
+    $SPH_BENCH_STATUS_DIR/rank<r>.stage for the self-launcher); a daemon thread checks two deadlines: the whole run
+    (`total_s`) and, optionally, the current stage's own budget.  On expiry:
+      * no complete line yet: rank 0 prints {"metric", "value": null, "error": "watchdog", "stage": ...} and EVERY rank
+        leaves with exit code 124 -- the launcher (torch.distributed.run or self_launch) reports rc != 0 within seconds
+        instead of sitting in a collective until its own timeout;
+      * a complete contract line was handed over with keep(line) (the tiled weak-scaling line is done, a SUPPLEMENTARY
+        object -- c4_dambreak -- hangs): rank 0 prints that line with the supplementary object replaced by
+        {"error": "watchdog", "stage": ...} and every rank leaves with exit code 0: the measurement is not thrown away.
+    All ranks arm the same budgets at the same collective points, so they expire together (os._exit: no atexit handler,
+    no destructor of a wedged communicator gets a chance to hang the exit)."""
+
+    def __init__(self, rank=0, world=1, total_s=900.0, metric="", enabled=True, take_sigterm=False):
+        import threading
+        import time
+        self._wake = None
+        if take_sigterm and threading.current_thread() is threading.main_thread():
+            # SIGTERM (the launcher ending the job) must be seen although the main thread may be stuck inside a C call, where a
+            # Python handler never gets to run: the C-level handler writes the signal number to a wake-up socket, whichever
+            # thread the kernel delivers it to, and a thread of ours reads it (_sigterm_thread).
+            import signal
+            import socket
+            try:
+                a, b = socket.socketpair()
+                a.setblocking(False)
+                b.setblocking(True)
+                signal.signal(signal.SIGTERM, lambda signum, frame: None)
+                signal.set_wakeup_fd(a.fileno(), warn_on_full_buffer=False)
+                self._wake = (a, b)
+            except (AttributeError, ValueError, OSError):
+                self._wake = None
+        take_sigterm = self._wake is not None
+        self._time = time
+        self.rank, self.world = int(rank), int(world)
+        self.metric = metric
+        self.t0 = time.monotonic()
+        self.deadline = self.t0 + float(total_s) if enabled and total_s > 0 else None
+        self.stage_deadline = None
+        self.stage_name = "start"
+        self.stage_t0 = self.t0
+        self.kept = None
+        self.kept_key = None
+        self.printed = False
+        self.lock = threading.Lock()
+        self.status_dir = None
+        import os
+        d = os.environ.get("SPH_BENCH_STATUS_DIR")
+        if d and os.path.isdir(d):
+            self.status_dir = d
+        self._write_status()
+        if self.deadline is not None:
+            self.thread = threading.Thread(target=self._watch, daemon=True, name="sph-bench-watchdog")
+            self.thread.start()
+        if take_sigterm:
+            threading.Thread(target=self._sigterm_thread, daemon=True, name="sph-bench-sigterm").start()
+
+    def _write_status(self):
+        if self.status_dir:
+            try:
+                import os
+                tmp = os.path.join(self.status_dir, f"rank{self.rank}.stage.tmp")
+                with open(tmp, "w") as f:
+                    f.write(self.stage_name)
+                os.replace(tmp, os.path.join(self.status_dir, f"rank{self.rank}.stage"))
+            except OSError:
+                pass
+
+    def stage(self, name, budget_s=None):
+        with self.lock:
+            now = self._time.monotonic()
+            self.stage_name, self.stage_t0 = str(name), now
+            self.stage_deadline = now + float(budget_s) if (budget_s and self.deadline is not None) else None
+        self._write_status()
+
+    def remaining(self):
+        if self.deadline is None:
+            return float("inf")
+        return max(self.deadline - self._time.monotonic(), 0.0)
+
+    def keep(self, line, supplementary_key):
+        """`line` is complete without line[supplementary_key]; if what follows hangs, it is what rank 0 prints."""
+        with self.lock:
+            self.kept, self.kept_key = line, supplementary_key
+
+    def emit(self, line):
+        """Print THE line (rank 0 calls this once); afterwards an expiry only ends the process."""
+        import json
+        with self.lock:
+            if self.printed:
+                return
+            self.printed = True
+        print(json.dumps(line), flush=True)
+
+    def _error_line(self, kind, name, detail):
+        return {"metric": self.metric, "value": None, "unit": "steps/s", "n_gpus": self.world, "error": kind, "stage": name,
+                "detail": detail, "rank": self.rank, "elapsed_s": round(self._time.monotonic() - self.t0, 1)}
+
+    def fail(self, detail, rc=1):
+        """This rank cannot go on (an exception in the bench): say where, and leave at once -- the peers are (or soon will
+        be) inside a collective with this rank; the launcher ends them when it sees this exit code.  If the contract line was
+        already complete (keep), rank 0 still prints it, the supplementary object carrying the error."""
+        import json
+        import os
+        import sys
+        with self.lock:
+            name, kept, key, printed = self.stage_name, self.kept, self.kept_key, self.printed
+            self.printed = True
+        print(f"[bench] rank {self.rank} failed in stage '{name}': {detail}", file=sys.stderr, flush=True)
+        if not printed and self.rank == 0:
+            if kept is not None:
+                kept = dict(kept)
+                kept[key] = {"error": "exception", "stage": name, "detail": detail}
+                print(json.dumps(kept), flush=True)
+                rc = 0
+            else:
+                print(json.dumps(self._error_line("exception", name, detail)), flush=True)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(rc)
+
+    def _sigterm_thread(self):
+        """The launcher is ending the job (a peer died): rank 0 leaves a line naming the stage it was stopped in."""
+        import json
+        import os
+        import signal
+        import sys
+        while True:
+            data = self._wake[1].recv(16)
+            if not data or signal.SIGTERM in data:
+                break
+        signum = int(signal.SIGTERM)
+        with self.lock:
+            name, kept, key, printed = self.stage_name, self.kept, self.kept_key, self.printed
+            self.printed = True
+        if not printed and self.rank == 0:
+            detail = f"stopped by the launcher (signal {signum}) in stage '{name}': another rank ended first"
+            if kept is not None:
+                kept = dict(kept)
+                kept[key] = {"error": "terminated", "stage": name, "detail": detail}
+                print(json.dumps(kept), flush=True)
+            else:
+                print(json.dumps(self._error_line("terminated", name, detail)), flush=True)
+        sys.stdout.flush()
+        os._exit(128 + signum)
+
+    def _watch(self):
+        import json
+        import os
+        import sys
+        while True:
+            self._time.sleep(0.25)
+            now = self._time.monotonic()
+            with self.lock:
+                over_total = self.deadline is not None and now >= self.deadline
+                over_stage = self.stage_deadline is not None and now >= self.stage_deadline
+                if not (over_total or over_stage):
+                    continue
+                name, since = self.stage_name, now - self.stage_t0
+                kept, key, printed = self.kept, self.kept_key, self.printed
+                self.printed = True          # from here on the main thread prints nothing more
+            why = (f"watchdog: rank {self.rank} spent {since:.0f} s in stage '{name}' "
+                   f"({'the run' if over_total else 'the stage'} exceeded its wall-clock budget; {now - self.t0:.0f} s since start)")
+            print(f"[bench] {why}", file=sys.stderr, flush=True)
+            rc = 124
+            if printed:
+                rc = 0                        # the line is out; only the teardown hung
+            elif kept is not None:
+                kept = dict(kept)
+                kept[key] = {"error": "watchdog", "stage": name, "detail": why}
+                if self.rank == 0:
+                    print(json.dumps(kept), flush=True)
+                rc = 0
+            elif self.rank == 0:
+                print(json.dumps(self._error_line("watchdog", name, why)), flush=True)
+            try:
+                sys.stdout.flush()
+                sys.stderr.flush()
+            finally:
+                os._exit(rc)
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_env(rank, world, port, status_dir=None, base=None):
+    """The environment of rank `rank` of a one-node job, as torch.distributed.run would set it."""
+    import os
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               GROUP_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SPH_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if status_dir:
+        env["SPH_BENCH_STATUS_DIR"] = status_dir
+    return env
+
+
+def self_launch(script, argv, world, total_s, metric="", popen=None, grace_s=20.0):
+    """`python bench.py --gpus N` WITHOUT a launcher: spawn the N ranks (one process per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* as torch.distributed.run sets them, rendezvous on 127.0.0.1), relay rank 0's stdout, and
+    supervise: a rank that dies takes the job down within `grace_s` (its peers would sit in a collective), the whole job
+    has `total_s` + a margin (each rank's own Watchdog fires first and names the stage).  Returns the exit code; prints
+    exactly one JSON line: rank 0's, or -- if no rank got to print one -- a fallback naming the rank, its exit code and
+    the stage its status file last named."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    import threading
+    import time
+    popen = popen or subprocess.Popen
+    port = free_port()
+    status_dir = tempfile.mkdtemp(prefix="sph_bench_")
+    procs = []
+    for r in range(world):
+        procs.append(popen([sys.executable, script, *argv], env=launch_env(r, world, port, status_dir),
+                           stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    out_lines = []
+
+    def pump():
+        for raw in procs[0].stdout:
+            out_lines.append(raw.decode(errors="replace").rstrip("\n"))
+    th = threading.Thread(target=pump, daemon=True)
+    th.start()
+    t0 = time.monotonic()
+    deadline = t0 + total_s + 45.0 if total_s > 0 else None
+    failed = None               # (rank, code) of the first rank that ended badly
+    t_fail = None
+    why = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        now = time.monotonic()
+        if failed is None:
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed, t_fail = bad[0], now
+        if failed is not None and now - t_fail > grace_s:
+            why = f"rank {failed[0]} exited with code {failed[1]}; its peers were still running {grace_s:.0f} s later and were stopped"
+            break
+        if deadline is not None and now > deadline:
+            why = f"the job exceeded {total_s:.0f} s (+45 s margin) and no rank's own watchdog ended it"
+            break
+        time.sleep(0.1)
+    if why is not None:         # stop exactly the processes started here
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(t_end - time.monotonic(), 0.1))
+            except subprocess.TimeoutExpired:
+                p.kill()
+    for p in procs:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    th.join(timeout=5)
+    codes = [p.returncode for p in procs]
+    stages = {}
+    for r in range(world):
+        try:
+            stages[r] = open(os.path.join(status_dir, f"rank{r}.stage")).read()
+        except OSError:
+            stages[r] = None
+    try:
+        for f in os.listdir(status_dir):
+            os.unlink(os.path.join(status_dir, f))
+        os.rmdir(status_dir)
+    except OSError:
+        pass
+    json_lines = [l for l in out_lines if l.startswith("{")]
+    for l in out_lines:
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    rc = 0
+    if any(c != 0 for c in codes):
+        rc = failed[1] if failed is not None else next(c for c in codes if c != 0)   # the rank that ended first, not the ones stopped here
+        if rc < 0:
+            rc = 128 - rc
+    if json_lines:
+        print(json_lines[-1], flush=True)
+        return rc
+    if why is None:
+        bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+        why = (f"rank {bad[0][0]} exited with code {bad[0][1]}" if bad else "rank 0 ended without printing a line")
+    print(json.dumps({"metric": metric, "value": None, "unit": "steps/s", "n_gpus": world, "error": "launch",
+                      "detail": why, "exit_codes": codes, "stage": stages.get(failed[0] if failed else 0),
+                      "stages": stages, "elapsed_s": round(time.monotonic() - t0, 1)}), flush=True)
+    return rc or 1

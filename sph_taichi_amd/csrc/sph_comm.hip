@@ -40,6 +40,8 @@ struct RcclApi {
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
     const char* (*GetErrorString)(ncclResult_t);
+    ncclResult_t (*CommCount)(const ncclComm_t, int*);
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*);
 };
 
 static RcclApi g_rccl = {};
@@ -77,6 +79,8 @@ static int rccl_load() {
     SPH_SYM(Recv, "ncclRecv")
     SPH_SYM(AllReduce, "ncclAllReduce")
     SPH_SYM(GetErrorString, "ncclGetErrorString")
+    SPH_SYM(CommCount, "ncclCommCount")
+    SPH_SYM(CommUserRank, "ncclCommUserRank")
 #undef SPH_SYM
     g_rccl = a;
     return 0;
@@ -328,6 +332,18 @@ int32_t sph_comm_sync(SphContext* c, SphComm* m) {
     SPH_HIP(c, hipSetDevice(c->device));
     SPH_HIP(c, hipStreamSynchronize(m->stream));
     harvest_halo(m);
+    return 0;
+}
+
+// What the communication library itself says about this communicator (ncclCommCount / ncclCommUserRank), not what the
+// host passed to sph_comm_create: a bench line can show that RCCL saw the N ranks of the job.
+int32_t sph_comm_info(SphContext* c, SphComm* m, int32_t* rank, int32_t* world) {
+    if (!c || !m || m->ctx != c || !rank || !world) return SPH_E_INVALID;
+    int r = -1, w = -1;
+    SPH_NCCL(c, g_rccl.CommCount(m->comm, &w));
+    SPH_NCCL(c, g_rccl.CommUserRank(m->comm, &r));
+    *rank = r;
+    *world = w;
     return 0;
 }
 

@@ -57,6 +57,7 @@ import copy
 import ctypes as C
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -329,6 +330,12 @@ class NativeTransport:
         self._call("sph_comm_all_reduce", C.c_void_p(t.data_ptr()), int(t.numel()), 0 if t.dtype == torch.float64 else 1)
         self.ps.sync()                                         # (the main stream waits for the communication stream)
         return t
+
+    def info(self):
+        """(rank, world) of the communicator as RCCL reports them (ncclCommUserRank / ncclCommCount)."""
+        r, w = C.c_int32(-1), C.c_int32(-1)
+        self._call("sph_comm_info", C.byref(r), C.byref(w))
+        return int(r.value), int(w.value)
 
     def halo_time(self):
         ms, n = C.c_double(), C.c_int64()
@@ -1121,7 +1128,57 @@ def _all_owned(s, red_dev):
     return [int(v) for v in t.tolist()]
 
 
-def run_c4_dambreak(args, rank, world, local_rank, scale=1.0):
+class _NoWatchdog:
+    """run_slab_bench / run_c4_dambreak outside bench.py (tests, tools): stage names go nowhere."""
+
+    def stage(self, name, budget_s=None):
+        pass
+
+    def keep(self, line, key):
+        pass
+
+    def remaining(self):
+        return float("inf")
+
+
+class CollectiveStageError(RuntimeError):
+    """Raised on EVERY rank when any rank failed a stage of a collectively guarded sequence."""
+
+
+def _ctl_device(local_rank):
+    """Where the job's small control tensors (ok flags, timings, owned counts) live: on the GPU under RCCL, on the host under
+    gloo (several ranks sharing one GPU)."""
+    import torch
+    import torch.distributed as dist
+    return torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def collective_stage(name, fn, ctl_dev, wd=None):
+    """Run this rank's share `fn` of stage `name`, then agree: ONE MAX all-reduce of (rank + 1 if it raised, else 0).  Either
+    every rank returns fn's value or every rank raises CollectiveStageError naming the stage and the (highest) failing
+    rank -- never one rank in an except-branch while its peers wait for it in the next stage's collectives (ADVICE r04
+    medium).  A failure INSIDE a stage that itself contains collectives can still leave the peers waiting; that is what
+    the bench's wall-clock watchdog is for."""
+    import sys
+    import torch
+    import torch.distributed as dist
+    if wd is not None:
+        wd.stage(name)
+    err, val = None, None
+    try:
+        val = fn()
+    except Exception as e:      # noqa: BLE001 -- any failure is reported to all
+        err = f"{type(e).__name__}: {e}"
+        print(f"[bench] rank {dist.get_rank()}: stage '{name}' failed: {err}", file=sys.stderr, flush=True)
+    f = torch.tensor([0 if err is None else dist.get_rank() + 1], dtype=torch.int64, device=ctl_dev)
+    dist.all_reduce(f, op=dist.ReduceOp.MAX)
+    bad = int(f.item())
+    if bad:
+        raise CollectiveStageError(f"stage '{name}' failed on rank {bad - 1}" + (f" (this rank: {err})" if err else ""))
+    return val
+
+
+def run_c4_dambreak(args, rank, world, local_rank, scale=1.0, wd=None):
     """BASELINE.json config 5 across the ranks of this job: 13,939,200 particles cut by particle count, one exchange and
     one sort per step, the cuts re-planned every `--recut-every` (default 10) steps.  Two states: the first collapse
     (W untimed + K timed steps from rest) and `settled` = after `--settled-after` further steps (the front has crossed the
@@ -1130,69 +1187,107 @@ def run_c4_dambreak(args, rank, world, local_rank, scale=1.0):
     import torch
     import torch.distributed as dist
     from .benchutil import REF_PARTICLES
+    wd = wd or _NoWatchdog()
     sd, n_global = c4_dambreak_scene(scale)
     recut = int(getattr(args, "recut_every", 0)) or 10
-    s = SlabSolver(sd, rank, world, device=local_rank, gather_impl=args.gather_impl, brick_shape=args.brick_shape,
-                   recut_every=recut, check_every=0)
-    transport = _choose_transport(s, rank, local_rank)
-    s.attach(transport)
-    s.initialize()
-    red_dev = torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else torch.device("cpu")
-    out = {"workload": "c4_dambreak_512x165x165_in_16x4x3.4", "particles": n_global, "recut_every": recut,
-           "transport": type(transport).__name__, "halo_layers": s.halo, "cuts_start": list(s.cuts),
-           "owned_start": _all_owned(s, red_dev)}
-    s.step(args.warmup)
-    s.host_ms = {k: 0 if k == "steps" else 0.0 for k in s.host_ms}
-    dt = _timed_steps(s, args.steps, red_dev)
-    out["from_rest"] = {"value": round(args.steps / dt * n_global / REF_PARTICLES, 3), "ms_per_step": round(dt / args.steps * 1e3, 4),
-                        "steps": args.steps, "warmup": args.warmup, "breakdown_ms": dict(_phase_events(s, min(args.steps, 20)), rank=0)}
-    settle = int(getattr(args, "settled_after", 0))
-    if settle > 0:
-        s.step(settle)
-        k = max(args.steps, 50)
-        dt = _timed_steps(s, k, red_dev)
+    red_dev = _ctl_device(local_rank)
+    box = {}
+
+    def stage(name, fn):
+        return collective_stage("c4_dambreak: " + name, fn, red_dev, wd)
+
+    def build():
+        box["s"] = SlabSolver(sd, rank, world, device=local_rank, gather_impl=args.gather_impl, brick_shape=args.brick_shape,
+                              recut_every=recut, check_every=0)
+
+    def attach():
+        s = box["s"]
+        box["t"] = _choose_transport(s, rank, local_rank)
+        s.attach(box["t"])
+        s.initialize()
+
+    try:
+        stage("build the slab contexts", build)
+        stage("transport + initialize", attach)
+        s, transport = box["s"], box["t"]
+        out = {"workload": "c4_dambreak_512x165x165_in_16x4x3.4", "particles": n_global, "recut_every": recut,
+               "transport": type(transport).__name__, "comm": _comm_info(transport), "halo_layers": s.halo,
+               "cuts_start": list(s.cuts), "owned_start": _all_owned(s, red_dev)}
+
+        def warm():
+            s.step(args.warmup)
+            s.host_ms = {k: 0 if k == "steps" else 0.0 for k in s.host_ms}
+        stage("warm-up steps", warm)
+        dt = stage("timed steps from rest", lambda: _timed_steps(s, args.steps, red_dev))
+        ev = stage("phase events", lambda: _phase_events(s, min(args.steps, 20)))
+        out["from_rest"] = {"value": round(args.steps / dt * n_global / REF_PARTICLES, 3), "ms_per_step": round(dt / args.steps * 1e3, 4),
+                            "steps": args.steps, "warmup": args.warmup, "breakdown_ms": dict(ev, rank=0)}
+        settle = int(getattr(args, "settled_after", 0))
+        if settle > 0:
+            stage(f"{settle} settling steps", lambda: s.step(settle))
+            k = max(args.steps, 50)
+            dt = stage("timed steps, settled", lambda: _timed_steps(s, k, red_dev))
+            owned = _all_owned(s, red_dev)
+            ev = stage("phase events, settled", lambda: _phase_events(s, 20))
+            out["settled"] = {"value": round(k / dt * n_global / REF_PARTICLES, 3), "ms_per_step": round(dt / k * 1e3, 4), "steps": k,
+                              "after_steps": s.steps_done - k - 20, "breakdown_ms": dict(ev, rank=0),
+                              "owned": owned, "imbalance": round(max(owned) / (n_global / world), 4), "cuts": list(s.cuts)}
         owned = _all_owned(s, red_dev)
-        out["settled"] = {"value": round(k / dt * n_global / REF_PARTICLES, 3), "ms_per_step": round(dt / k * 1e3, 4), "steps": k,
-                          "after_steps": s.steps_done - k, "breakdown_ms": dict(_phase_events(s, 20), rank=0),
-                          "owned": owned, "imbalance": round(max(owned) / (n_global / world), 4), "cuts": list(s.cuts)}
-    owned = _all_owned(s, red_dev)
-    out["owned_end"] = owned
-    out["cuts_end"] = list(s.cuts)
-    out["recut_events_rank0"] = int(s.stats.get("recuts", 0))
-    out["conserved"] = sum(owned) == n_global
-    out["imbalance_start"] = round(max(out["owned_start"]) / (n_global / world), 4)
-    out["imbalance_end"] = round(max(owned) / (n_global / world), 4)
-    out["rank0_host_ms_per_step"] = {k_: round(v / max(s.host_ms["steps"], 1), 4) for k_, v in s.host_ms.items() if k_ != "steps"}
+        out["owned_end"] = owned
+        out["cuts_end"] = list(s.cuts)
+        out["recut_events_rank0"] = int(s.stats.get("recuts", 0))
+        out["conserved"] = sum(owned) == n_global
+        out["imbalance_start"] = round(max(out["owned_start"]) / (n_global / world), 4)
+        out["imbalance_end"] = round(max(owned) / (n_global / world), 4)
+        out["rank0_host_ms_per_step"] = {k_: round(v / max(s.host_ms["steps"], 1), 4) for k_, v in s.host_ms.items() if k_ != "steps"}
+        if isinstance(transport, NativeTransport):
+            ms, n = transport.halo_time()
+            out["halo_device_ms"] = round(ms / max(n, 1), 4)
+        st = _lib.SphStats()
+        s.ps._call("sph_get_stats", st)
+        out["rank0_neighbourhood"] = {"max_list_entries": st.max_list, "list_overflow_targets": st.list_overflow_targets,
+                                      "lds_overflow_targets": st.lds_overflow_targets, "max_cell_occupancy": st.max_cell_occupancy}
+        return out
+    finally:
+        wd.stage("c4_dambreak: teardown")
+        t = box.get("t")
+        if isinstance(t, NativeTransport):
+            t.close()
+        if box.get("s") is not None:
+            box["s"].close()
+
+
+def _comm_info(transport):
+    """What the communication library itself reports about the communicator the records travel on."""
+    import torch.distributed as dist
     if isinstance(transport, NativeTransport):
-        ms, n = transport.halo_time()
-        out["halo_device_ms"] = round(ms / max(n, 1), 4)
-        transport.close()
-    st = _lib.SphStats()
-    s.ps._call("sph_get_stats", st)
-    out["rank0_neighbourhood"] = {"max_list_entries": st.max_list, "list_overflow_targets": st.list_overflow_targets,
-                                  "lds_overflow_targets": st.lds_overflow_targets, "max_cell_occupancy": st.max_cell_occupancy}
-    s.close()
-    return out
+        r, w = transport.info()
+        return {"library": "RCCL behind the C ABI (sph_comm.hip: ncclCommInitRank)", "world": w, "rank": r}
+    return {"library": f"torch.distributed ({dist.get_backend()}) P2P", "world": dist.get_world_size(), "rank": dist.get_rank()}
 
 
-def run_slab_bench(args, rank, world, local_rank):
+def run_slab_bench(args, rank, world, local_rank, wd=None):
+    """`bench.py --gpus N` on every rank.  `wd` (benchutil.Watchdog) is told what the rank is doing, so that a hang is
+    reported with its stage; the tiled line is handed to it (keep) BEFORE the supplementary c4_dambreak object starts."""
     import torch
     import torch.distributed as dist
     from .benchutil import gpu_preheat, _HEAT, REF_PARTICLES, HBM_PEAK_GBS
+    wd = wd or _NoWatchdog()
     dfsph = getattr(args, "solver", "wcsph") == "dfsph"
     c4_line = getattr(args, "workload", "") == "c4_dambreak"
-    red_dev = torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else torch.device("cpu")
+    red_dev = _ctl_device(local_rank)
     metric = ("DFSPH steps/sec at 1.74 M particles (supplementary)" if dfsph else
               "WCSPH steps/sec at 1.74 M particles (+ ms/step breakdown sort/neighbour/force)")
     if c4_line and not dfsph:
         # the named 8-GPU workload as the line itself
-        c4 = run_c4_dambreak(args, rank, world, local_rank, scale=float(os.environ.get("SPH_C4_SCALE", "1.0")))
+        c4 = run_c4_dambreak(args, rank, world, local_rank, scale=float(os.environ.get("SPH_C4_SCALE", "1.0")), wd=wd)
         fr = c4["from_rest"]
         return {"metric": metric, "value": fr["value"], "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": fr["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
                 "data": "synthetic", "preheat_ms": 0.0,
                 "config": {"workload": c4["workload"], "particles": c4["particles"], "recut_every": c4["recut_every"],
-                           "backend": dist.get_backend(), "transport": c4["transport"],
+                           "backend": dist.get_backend(), "transport": c4["transport"], "comm": c4["comm"],
+                           "particles_owned_per_rank": c4["owned_end"],
                            "parallelism": f"x-slab x{world} cut by particle count, travelling cuts, 1 exchange/step"},
                 "steps_per_s_job": round(fr["value"] * REF_PARTICLES / c4["particles"], 3),
                 "breakdown_ms": dict(fr["breakdown_ms"], halo_device=c4.get("halo_device_ms")),
@@ -1203,15 +1298,22 @@ def run_slab_bench(args, rank, world, local_rank):
         sd["Configuration"]["timeStepSize"] = 0.004
     # (check_every = 0: the conservation guard is a blocking all-reduce + host read; the bench scene is balanced and
     # slow -- no particle can outrun the halo -- so the guard stays out of the timed region)
+    wd.stage("tiled: build the slab contexts")
     s = SlabSolver(sd, rank, world, device=local_rank, gather_impl=args.gather_impl, brick_shape=args.brick_shape,
                    recut_every=getattr(args, "recut_every", 0), check_every=0)
+    wd.stage("tiled: transport negotiation")
     transport = _choose_transport(s, rank, local_rank)
     s.attach(transport)
+    comm = _comm_info(transport)
+    wd.stage("tiled: initialize (first exchange + sort)")
     s.initialize()
     gpu_preheat(local_rank, float(getattr(args, "preheat_ms", 0.0)))    # clock ramp after the host-side set-up: see gpu_preheat
+    wd.stage("tiled: warm-up steps")
     s.step(args.warmup)
     s.host_ms = {k: 0 if k == "steps" else 0.0 for k in s.host_ms}
+    wd.stage("tiled: timed steps")
     dt = _timed_steps(s, args.steps, red_dev)
+    wd.stage("tiled: owned counts + phase events")
     owned = _all_owned(s, red_dev)
     host_ms = dict(s.host_ms)
     phases = {"sort": 0.0, "neighbour": 0.0, "force": 0.0, "integrate": 0.0, "sum_of_phases": 0.0}
@@ -1243,7 +1345,8 @@ def run_slab_bench(args, rank, world, local_rank):
         "config": {"workload": f"c3p_tiled_x{world}_{246 * world}x74x96", "particles": n_global,
                    "particles_owned_sum": sum(owned), "particles_owned_per_rank": owned, "cuts": s.cuts, "halo_layers": s.halo,
                    "sent_records_per_step": round(s.stats["sent"] / max(args.steps + args.warmup + 1, 1), 1),
-                   "backend": dist.get_backend(), "transport": type(transport).__name__, "recut_every": s.recut_every,
+                   "backend": dist.get_backend(), "transport": type(transport).__name__, "comm": comm,
+                   "recut_every": s.recut_every,
                    "rank0_host_ms_per_step": {k: round(v / max(host_ms["steps"], 1), 4)
                                               for k, v in host_ms.items() if k != "steps"},
                    "parallelism": f"x-slab x{world}, 1 exchange/step over "
@@ -1265,13 +1368,35 @@ def run_slab_bench(args, rank, world, local_rank):
         line["breakdown_ms"]["halo_device"] = round(ms / max(n, 1), 4)
         line["breakdown_ms"]["note"] += ("; halo_device: mean duration of the payload exchange on rank 0's communication "
                                          "stream (HIP events around ncclGroupStart..End)")
+    wd.stage("tiled: teardown")
+    if isinstance(transport, NativeTransport):
         transport.close()
     s.close()
     # ... and, in the same driver command, BASELINE.json's named 8-GPU workload in its own geometry:
-    # 13.9 M particles whatever N is (strong scaling), unbalanced start, cuts re-planned every 10 steps, two states
+    # 13.9 M particles whatever N is (strong scaling), unbalanced start, cuts re-planned every 10 steps, two states.
+    # It is SUPPLEMENTARY: the tiled line above is complete and is handed to the watchdog first, so that nothing this
+    # object does -- an exception on one rank (agreed on collectively, stage by stage: collective_stage), a hang (its own
+    # wall-clock budget) -- can cost the contract line.
     if not dfsph and int(getattr(args, "c4", 1)):
+        line["c4_dambreak"] = None
+        wd.keep(line, "c4_dambreak")
+        budget = min(float(getattr(args, "c4_budget_s", 300.0)), max(wd.remaining() - 20.0, 1.0))
+        t_end = time.monotonic() + budget
+
+        class _Budgeted:            # every stage of the object inherits what is left of the object's budget
+            def stage(self, name, budget_s=None):
+                wd.stage(name, budget_s=max(t_end - time.monotonic(), 1.0) if budget != float("inf") else None)
+
+            def keep(self, line, key):
+                pass
+
+            def remaining(self):
+                return wd.remaining()
         try:
-            line["c4_dambreak"] = run_c4_dambreak(args, rank, world, local_rank, scale=float(os.environ.get("SPH_C4_SCALE", "1.0")))
-        except Exception as e:      # noqa: BLE001 -- the tiled line above is the contract's; this object must never cost it
+            line["c4_dambreak"] = run_c4_dambreak(args, rank, world, local_rank, scale=float(os.environ.get("SPH_C4_SCALE", "1.0")),
+                                                  wd=_Budgeted())
+            line["c4_dambreak"]["budget_s"] = round(budget, 1) if budget != float("inf") else None
+        except Exception as e:      # noqa: BLE001 -- CollectiveStageError on every rank alike, or a failure outside the guarded stages
             line["c4_dambreak"] = {"error": f"{type(e).__name__}: {e}"}
+        wd.stage("c4_dambreak: done")
     return line

@@ -2,7 +2,7 @@
 //
 // Why: RCCL refuses two ranks on one GPU, and the development boxes have one GPU.  The slab exchange behind the C ABI
 // (sph_taichi_amd/csrc/sph_comm.hip) had therefore only ever run as ONE rank talking to itself; the ordering it relies
-// on BETWEEN ranks had never met a second process.  This library exports the nine RCCL entry points sph_comm.hip binds
+// on BETWEEN ranks had never met a second process.  This library exports the eleven RCCL entry points sph_comm.hip binds
 // (same prototypes: it includes the real <rccl/rccl.h>, so the compiler checks them) and moves the bytes between
 // PROCESSES that share one GPU.  `SPH_RCCL_LIB=<path to this .so>` makes sph_comm.hip dlopen it instead of librccl.
 //
@@ -430,6 +430,18 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
     if (FILE* f = fopen("/dev/urandom", "rb")) { if (fread(&r, sizeof(r), 1, f) != 1) r = 0; fclose(f); }
     const char* dir = getenv("FAKE_RCCL_DIR");
     snprintf(id->internal, sizeof(id->internal), "%s/fake_rccl_%d_%08x", dir ? dir : "/tmp", (int)getpid(), r);
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommCount(const ncclComm_t c, int* count) {
+    if (!c || !count) return ncclInvalidArgument;
+    *count = c->world;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommUserRank(const ncclComm_t c, int* rank) {
+    if (!c || !rank) return ncclInvalidArgument;
+    *rank = c->rank;
     return ncclSuccess;
 }
 

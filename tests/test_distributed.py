@@ -545,35 +545,73 @@ def test_native_exchange_reports_a_missing_peer_instead_of_hanging(tmp_path):
     assert p[0].returncode != 0 and "fake_rccl" in logs[0] and "timeout" in logs[0], logs[0][-2000:]
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("transport", ["torch", "native"])
-def test_bench_two_ranks_on_one_gpu(transport, tmp_path):
-    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank) -- here with both ranks
-    on the one GPU there is (SPH_DIST_BACKEND=gloo), once over the torch transport and once over NativeTransport through
-    the librccl stand-in, negotiated collectively: the tiled weak-scaling line AND BASELINE.json's config 5 (`c4_dambreak`,
-    shrunk by SPH_C4_SCALE so that it fits a test) with re-cut, a settled state, per-rank owned counts and conservation."""
+def _bench_two_ranks(transport, launcher, extra=(), tmp_path=None):
     root = os.path.dirname(HERE)
     env = dict(os.environ, SPH_DIST_BACKEND="gloo", SPH_C4_SCALE="0.2", SPH_TRANSPORT=transport)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
     if transport == "native":
         env.update(_fake_rccl_env(slot_bytes=1 << 20))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3",
-           "--settled-after", "60", "--preheat-ms", "0"]
+    args = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--settled-after", "60",
+            "--preheat-ms", "0", "--watchdog-s", "420", *extra]
+    if launcher == "torchrun":      # as the driver launches N > 1: torch.distributed.run, one process per rank
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + args
+    else:                           # as the driver launches N = 1: plain python -- bench.py spawns its ranks itself
+        cmd = [sys.executable] + args
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600, cwd=root)
-    assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    return p, lines
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transport,launcher", [("torch", "torchrun"), ("native", "self")])
+def test_bench_two_ranks_on_one_gpu(transport, launcher, tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank) AND with no launcher at
+    all (`python bench.py --gpus 2`: bench.py spawns its own ranks, VERDICT r04 "next" #2a) -- here with both ranks on the one
+    GPU there is (SPH_DIST_BACKEND=gloo), once over the torch transport and once over NativeTransport through the librccl
+    stand-in, negotiated collectively: the tiled weak-scaling line AND BASELINE.json's config 5 (`c4_dambreak`, shrunk by
+    SPH_C4_SCALE so that it fits a test) with re-cut, a settled state, per-rank owned counts and conservation."""
+    p, lines = _bench_two_ranks(transport, launcher)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
     assert len(lines) == 1, p.stdout.decode()[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["particles"] == 2 * 1_747_584
     assert d["config"]["transport"] == ("NativeTransport" if transport == "native" else "TorchTransport"), d["config"]
+    assert d["config"]["backend"] == "gloo" and d["config"]["comm"]["world"] == 2 and d["config"]["comm"]["rank"] == 0
     assert sum(d["config"]["particles_owned_per_rank"]) == d["config"]["particles"]
     c4 = d["c4_dambreak"]
     assert "error" not in c4, c4
     assert c4["conserved"] and c4["recut_every"] == 10 and c4["from_rest"]["value"] > 0 and c4["settled"]["value"] > 0
-    assert sum(c4["owned_end"]) == c4["particles"] and len(c4["owned_end"]) == 2
+    assert sum(c4["owned_end"]) == c4["particles"] and len(c4["owned_end"]) == 2 and c4["comm"]["world"] == 2
     assert c4["imbalance_end"] <= 1.25, c4
     if transport == "native":
         assert c4["transport"] == "NativeTransport" and c4["halo_device_ms"] >= 0.0 and "halo_device" in d["breakdown_ms"]
+        assert "RCCL behind the C ABI" in c4["comm"]["library"]
+
+
+@pytest.mark.gpu
+def test_bench_keeps_the_tiled_line_when_the_c4_object_hangs(tmp_path):
+    """ADVICE r04 medium / VERDICT r04 "next" #2c: the supplementary c4_dambreak object gets a wall-clock budget it cannot
+    meet (the stand-in for a hang inside it): both ranks' watchdogs end the job, rank 0 prints the FINISHED tiled line with
+    c4_dambreak = {error: watchdog, stage: ...}, exit code 0."""
+    p, lines = _bench_two_ranks("torch", "self", extra=("--c4-budget-s", "0.5"))
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and sum(d["config"]["particles_owned_per_rank"]) == d["config"]["particles"]
+    assert d["c4_dambreak"]["error"] == "watchdog" and d["c4_dambreak"]["stage"].startswith("c4_dambreak:"), d["c4_dambreak"]
+
+
+@pytest.mark.gpu
+def test_bench_hang_before_the_line_is_rc_124_and_names_the_stage(tmp_path):
+    """A whole-job budget that ends inside the tiled run: no line is complete, so the job must end with rc != 0 and ONE
+    JSON line naming the stage (never a silent hang until the driver's own timeout)."""
+    p, lines = _bench_two_ranks("torch", "self", extra=("--watchdog-s", "25", "--steps", "200000"))
+    assert p.returncode == 124, (p.returncode, p.stderr.decode()[-2000:])
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["error"] == "watchdog" and d["stage"] and d["n_gpus"] == 2, d
 
 
 @pytest.mark.gpu

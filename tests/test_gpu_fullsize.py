@@ -22,40 +22,9 @@ import scenes
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-CFG = dict(scenes.BASE_CFG, domainEnd=[5.0, 3.0, 2.0])
+from sph_taichi_amd.workloads import dragon_bath_scene, armadillo_equiv_scene, DEMO_CFG      # noqa: E402
 
-
-def dragon_bath_scene():
-    """data/scenes/dragon_bath.json with the dragon's voxel set taken from the fixture."""
-    return {
-        "Configuration": copy.deepcopy(CFG),
-        "RigidBodies": [{"objectId": 1, "voxelizedPointsFile": os.path.join(GOLDEN, "dragon_bath_body.npy"),
-                         "translation": [3.5, 0.05, 1.0], "rotationAxis": [0, 1, 0], "rotationAngle": 0,
-                         "scale": [1, 1, 1], "velocity": [0.0, 0.0, 0.0], "density": 1000.0,
-                         "color": [255, 255, 255], "isDynamic": False}],
-        "FluidBlocks": [{"objectId": 0, "start": [0.1, 0.1, 0.5], "end": [1.2, 2.9, 1.6],
-                         "translation": [0.2, 0.0, 0.2], "scale": [1, 1, 1], "velocity": [0.0, -1.0, 0.0],
-                         "density": 1000.0, "color": [50, 100, 200]}],
-    }
-
-
-def armadillo_equiv_scene(body_y=1.74):
-    """data/scenes/armadillo_bath_dynamic.json with a stand-in mesh (the armadillo blob is missing from the
-    reference checkout) and the bodies lowered to just above the fluid so contact happens within ~10 steps."""
-    bodies = []
-    for oid, x, rho, col in ((1, 4.0, 7874.0, [255, 255, 255]), (2, 2.5, 1700.0, [255, 100, 50]),
-                             (3, 1.0, 300.0, [100, 100, 50])):
-        bodies.append({"objectId": oid, "voxelizedPointsFile": os.path.join(GOLDEN, "armadillo_standin.npy"),
-                       "translation": [x, body_y, 1.2], "rotationAxis": [0, 1, 0], "rotationAngle": 180,
-                       "scale": [0.25, 0.25, 0.25], "velocity": [0.0, -5.0, 0.0], "density": rho, "color": col,
-                       "isDynamic": True})
-    return {
-        "Configuration": copy.deepcopy(CFG),
-        "RigidBodies": bodies,
-        "FluidBlocks": [{"objectId": 0, "start": [0.04, 0.04, 0.04], "end": [4.96, 1.50, 1.96],
-                         "translation": [0.0, 0.0, 0.0], "scale": [1, 1, 1], "velocity": [0.0, 0.0, 0.0],
-                         "density": 1000.0, "color": [50, 100, 200]}],
-    }
+CFG = DEMO_CFG
 
 
 def _threads():

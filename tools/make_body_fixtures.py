@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Voxelise the reference's Dragon_50k.obj into small point-set fixtures (container only: needs
 /root/reference).  The GPU box has no /root/reference, so the full-size parity scenes load these:
-  tests/golden/dragon_bath_body.npy     dragon as in data/scenes/dragon_bath.json (scale 1, rot 0), untranslated
-  tests/golden/armadillo_standin.npy    dragon scaled 0.65, rotated 180 deg about y: stand-in for the missing
+  sph_taichi_amd/data/bodies/dragon_bath_body.npy     dragon as in data/scenes/dragon_bath.json (scale 1, rot 0), untranslated
+  sph_taichi_amd/data/bodies/armadillo_standin.npy    dragon scaled 0.65, rotated 180 deg about y: stand-in for the missing
                                         armadillo_small.obj of armadillo_bath_dynamic.json (~5.4 k particles)
 Points are stored WITHOUT the scene translation; the loader adds it (translations that are multiples of
 d = 0.02 keep the voxel lattice of the original recipe; dragon_bath's (3.5, 0.05, 1.0) is applied before
@@ -18,7 +18,7 @@ from sph_taichi_amd import voxelizer  # noqa: E402
 
 REF = "/root/reference"
 OBJ = os.path.join(REF, "data/models/Dragon_50k.obj")
-out = os.path.join(ROOT, "tests", "golden")
+out = os.path.join(ROOT, "sph_taichi_amd", "data", "bodies")
 
 body = {"geometryFile": OBJ, "scale": [1, 1, 1], "translation": [3.5, 0.05, 1.0], "rotationAxis": [0, 1, 0],
         "rotationAngle": 0}

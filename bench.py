@@ -368,7 +368,7 @@ def main():
         solver.step(args.warmup)
         solver.dt[None] = 0.0
         for mask, what in [(0, "full"), (1, "no phase 2"), (2, "no list write-out (force sweep reads stale lists)"),
-                           (128, "force: no neighbour gather (only in a -DSPH_PROFILE_FORCE build)"),
+                           (128, "force: no neighbour gather (profiling build, -DSPH_PROFILE)"),
                            (16, "filter only, no hit emitted"), (32, "no pair term in the emission loop"), (34, "emission: bit loop only"),
                            (4, "no phase 1"), (7, "staging + target setup only")]:
             ps.set_option(_lib.OPT_DEBUG_ABLATE, mask)
@@ -611,6 +611,10 @@ def main():
             line["with_bodies"] = with_bodies(args, local_rank)
         except Exception as e:      # noqa: BLE001 -- a supplementary object never costs the headline line
             line["with_bodies"] = {"error": f"{type(e).__name__}: {e}"}
+    # ... and as top-level scalars, so that a reader of the parsed line alone sees all four numbers (VERDICT r04 "weak" #8):
+    # value (mean of the preheated blocks from rest) >= value_single_block >= value_with_bodies / value_settled
+    line["value_settled"] = line["settled"]["value"] if isinstance(line.get("settled"), dict) else None
+    line["value_with_bodies"] = (line["with_bodies"].get("value") if isinstance(line.get("with_bodies"), dict) else None)
     if args.cpu_steps > 0:
         line["cpu_baseline"] = cpu_baseline(sd, args.cpu_steps)
     else:

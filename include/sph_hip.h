@@ -142,7 +142,12 @@ enum SphOption {
     SPH_OPT_EXACT_MATH = 12    /* A/B of the fast-math choice (never the default): 1 = the brick sweeps of the fused WCSPH step
                                   (density + EOS, force) evaluate r.norm(), r / (|r| h), x / y with IEEE sqrt and divide
                                   as the reference's f32 expressions do, instead of v_rsq_f32 / v_rcp_f32 (~1 ulp).
-                                  profiles/r04_parity_fastmath_ab.json holds the two builds side by side. */
+                                  profiles/r04_parity_fastmath_ab.json holds the two builds side by side.
+                                  RESTRICTION: exact-math instances exist for the uniform-fluid step only (GM_DENSITY_EOS
+                                  inline / lean and GM_FORCE_FUSED_U); scenes with any solid run the general sweeps, whose
+                                  pair physics keeps v_rsq / v_rcp, and so do the cell-walk fallbacks.  sph_get_option
+                                  reports the EFFECTIVE state: 1 only while the context's step actually runs those
+                                  instances (SPH_OPT_UNIFORM_FLUID_STATE == 1), else 0. */
 };
 #define SPH_VAR_GROUPS 1   /* density: all nine runs filtered first (masks in registers), hits emitted centre run / edge runs / corner
                               runs, each group by descending hit count */
@@ -280,7 +285,9 @@ int32_t sph_slab_advance(SphContext* ctx, int32_t keep_first, int32_t keep_count
  * update, written to dstL / dstR, arrays untouched); an event; the force sweep of the remaining owned layers; the
  * in-place advect.  sph_slab_wait_pack blocks until the packers are done -- the caller starts the exchange while
  * the interior force sweep is still running.  (With the advect fused into the interior sweep's finish the interior
- * particles' `acceleration` field is not materialised by this call: only the boundary sets' is, for the packers.) */
+ * particles' `acceleration` field is not materialised by this call: only the boundary sets' is, for the packers;
+ * sph_download(SPH_F_ACCELERATION) then fails with SPH_E_STATE until something writes every acceleration again:
+ * sph_compute_non_pressure_forces (+ sph_compute_pressure_forces), sph_step, or an upload.) */
 int32_t sph_slab_forces(SphContext* ctx, int32_t bl_lo, int32_t bl_hi, int32_t br_lo, int32_t br_hi,
                         int32_t firstL, int32_t nL, void* dstL, int32_t firstR, int32_t nR, void* dstR);
 int32_t sph_slab_wait_pack(SphContext* ctx);

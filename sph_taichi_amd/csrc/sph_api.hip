@@ -280,7 +280,9 @@ int32_t sph_get_option(const SphContext* c, int32_t option, int32_t* value) {
         case SPH_OPT_UNIFORM_FLUID: *value = c->opt_uniform; return 0;
         case SPH_OPT_SORT_BY_PID: *value = c->opt_sort_by_pid; return 0;
         case SPH_OPT_RIGID_BATCH: *value = c->opt_rigid_batch; return 0;
-        case SPH_OPT_EXACT_MATH: *value = c->opt_exact_math; return 0;
+        // the EFFECTIVE state: exact-math instances exist for the uniform-fluid step only (sph_hip.h); a scene found not to
+        // be one runs the general sweeps with v_rsq / v_rcp whatever was requested, and an A/B must be able to see that
+        case SPH_OPT_EXACT_MATH: *value = (c->opt_exact_math && c->uniform_state != 0) ? 1 : 0; return 0;
         case SPH_OPT_KERNEL_VARIANT: *value = c->opt_variant; return 0;
         case SPH_OPT_UNIFORM_FLUID_STATE: *value = c->uniform_state; return 0;
     }
@@ -332,6 +334,7 @@ int32_t sph_upload(SphContext* c, int32_t field, const void* host, size_t bytes)
     SPH_HIP(c, hipSetDevice(c->device));
     if (bytes == 0) return 0;
     if (field == SPH_F_DENSITY || field == SPH_F_PRESSURE) { int rc0 = sph_ensure_aux(c); if (rc0) return rc0; }
+    if (field == SPH_F_ACCELERATION) c->acc_partial = false;
     if (field == SPH_F_RIGID_REST_CM) {
         SPH_HIP(c, hipMemcpyAsync(c->rigid_rest_cm, host, bytes, hipMemcpyHostToDevice, c->stream));
         SPH_HIP(c, hipStreamSynchronize(c->stream));
@@ -353,6 +356,10 @@ int32_t sph_download(SphContext* c, int32_t field, void* host, size_t bytes) {
     if (bytes != field_bytes(c, field)) return sph_fail(c, SPH_E_INVALID, "sph_download: size mismatch");
     SPH_HIP(c, hipSetDevice(c->device));
     if (bytes == 0) return 0;
+    if (field == SPH_F_ACCELERATION && c->acc_partial)
+        return sph_fail(c, SPH_E_STATE, "sph_download(acceleration): the last sph_slab_forces consumed the interior particles' accelerations "
+                                        "in its fused finish and did not write them out (stale values would be returned); call "
+                                        "sph_compute_non_pressure_forces + sph_compute_pressure_forces, or run with SPH_OPT_FUSED_STEP 0");
     const void* src = c->stage;
     if (field == SPH_F_GRID_PARTICLES_NUM) src = c->cell_end;
     else if (field == SPH_F_RIGID_REST_CM) src = c->rigid_rest_cm;
@@ -465,6 +472,7 @@ int32_t sph_compute_non_pressure_forces(SphContext* c) {
     ENTER(c);
     int rc = need_sorted(c, "sph_compute_non_pressure_forces");
     rc = rc ? rc : sph_ensure_aux(c);
+    c->acc_partial = false;   // every particle's acceleration is (re)written from here on
     return rc ? rc : sphk_gather(c, GM_NONPRESSURE);
 }
 
@@ -657,6 +665,7 @@ int32_t sph_step(SphContext* c, int32_t n_steps, const int32_t* dynamic_ids, int
     if (n_steps < 0 || n_dynamic < 0 || (n_dynamic > 0 && !dynamic_ids)) return sph_fail(c, SPH_E_INVALID, "sph_step: bad arguments");
     int rc = refresh_dyn(c);
     if (rc) return rc;
+    if (n_steps > 0) c->acc_partial = false;   // the call's last step writes every acceleration out
     for (int it = 0; it < n_steps; ++it) {
         hipEvent_t* ev = nullptr;
         const bool timing = sph_timed_step(c);  // SPH_OPT_TIMING k: every k-th step carries the five events
@@ -917,6 +926,7 @@ int32_t sph_slab_forces(SphContext* c, int32_t bl_lo, int32_t bl_hi, int32_t br_
     rc = sphk_gather_layers(c, GM_FORCE_FUSED, bl_hi, br_lo, 0, 0);
     c->fuse_advect = 0;
     c->skip_acc = 0;
+    c->acc_partial = fuse;
     if (rc) return rc;
     if (!no_boundary) SPH_HIP(c, hipStreamWaitEvent(c->stream, c->ev_pack, 0));  // the packers read what the advect overwrites
     hipEvent_t* ev = c->slab_ev_open ? c->ev[c->ev_used] : nullptr;
@@ -1122,6 +1132,7 @@ int32_t sph_dfsph_step(SphContext* c, int32_t n_steps, const int32_t* dynamic_id
     if (n_steps < 0 || n_dynamic < 0 || (n_dynamic > 0 && !dynamic_ids)) return sph_fail(c, SPH_E_INVALID, "sph_dfsph_step: bad arguments");
     int rc = refresh_dyn(c);
     if (rc) return rc;
+    if (n_steps > 0) c->acc_partial = false;
     for (int it = 0; it < n_steps; ++it) {
         hipEvent_t* ev = nullptr;
         const bool timing = sph_timed_step(c);  // SPH_OPT_TIMING k: every k-th step carries the five events

@@ -155,6 +155,8 @@ struct SphContext {
     int opt_variant;     // SPH_OPT_KERNEL_VARIANT (bit mask of SPH_VAR_*)
     int fuse_advect;     // set around the force launch of sph_step when the advect can ride in its finish
     int skip_acc;        // set by sph_step for every step but the last of a call: the fused force finish keeps its acceleration to itself
+    bool acc_partial;    // sph_slab_forces with the interior advect fused: the interior targets' accelerations were consumed in the
+                         // force finish and never written out; sph_download(ACCELERATION) refuses until something writes them all
     bool aux_stale;      // density / pressure of the fluid live in eos2 (written by the lean density finish), not yet in aux:
                          // sph_ensure_aux folds them in before anything reads aux.y / aux.z or a reference-API sort moves the records
     int opt_uniform;     // SPH_OPT_UNIFORM_FLUID: -1 auto, 0 off, 1 check once

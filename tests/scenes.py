@@ -159,3 +159,18 @@ def ps_by_pid(ps, name):
     out = np.empty_like(arr)
     out[ps.pid.to_numpy()] = arr
     return out
+
+
+def evidence_path(name):
+    """Where a test may leave a measured curve / error table as EVIDENCE (copied to profiles/ by the round's GPU script):
+    $SPH_TEST_EVIDENCE_DIR/name, or None when the variable is unset -- a plain `pytest` run writes nothing outside its
+    tmp_path."""
+    import os
+    d = os.environ.get("SPH_TEST_EVIDENCE_DIR")
+    if not d:
+        return None
+    try:
+        os.makedirs(d, exist_ok=True)
+    except OSError:
+        return None
+    return os.path.join(d, name)

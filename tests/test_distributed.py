@@ -458,9 +458,10 @@ def _fake_rccl_env(slot_bytes=65536):
     """SPH_RCCL_LIB -> the stand-in for librccl (tests/fake_rccl/): several PROCESSES on one GPU run the exchange of
     csrc/sph_comm.hip.  Small ring slots, so that record payloads span several of them; short timeouts, so that a
     protocol bug is a failed test within a minute, never a hung box."""
-    sys.path.insert(0, os.path.join(HERE, "fake_rccl"))
-    import build as fake_build
-    sys.path.pop(0)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sph_fake_rccl_build", os.path.join(HERE, "fake_rccl", "build.py"))
+    fake_build = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fake_build)
     return {"SPH_RCCL_LIB": fake_build.build(), "FAKE_RCCL_SLOT_BYTES": str(slot_bytes), "FAKE_RCCL_SLOTS": "3",
             "FAKE_RCCL_TIMEOUT_S": "25"}
 

@@ -247,10 +247,12 @@ def test_hip_reproduces_big_reference_execution(path):
         gi = ps.grid_ids.to_numpy()
         same = np.array_equal(gi, z[f"step{n}/grid_ids"])
         mismatches[str(n)] = int((gi != z[f"step{n}/grid_ids"]).sum())
-        assert same or np.mean(gi != z[f"step{n}/grid_ids"]) <= 1e-3, f"cell ids after step {n}"
-        if same:        # same cells => same (stable) order: compare in place
-            assert scenes.rel_l2(ps.x.to_numpy(), z[f"step{n}/x"]) <= 1e-4, f"rel-L2(x) after step {n}"
-            assert scenes.rel_l2(ps.v.to_numpy(), z[f"step{n}/v"]) <= 2e-3, f"rel-L2(v) after step {n}"
+        # every cell id of every kept stage equals the reference execution's (0 differing ids were ever measured,
+        # profiles/r04b_big_fixture_cell_id_mismatches.json; VERDICT r04 "weak" #4: no allowance -- a real tie must surface)
+        assert same, f"{mismatches[str(n)]} cell ids differ from the reference execution after step {n}"
+        # same cells => same (stable) order: compare in place
+        assert scenes.rel_l2(ps.x.to_numpy(), z[f"step{n}/x"]) <= 1e-4, f"rel-L2(x) after step {n}"
+        assert scenes.rel_l2(ps.v.to_numpy(), z[f"step{n}/v"]) <= 2e-3, f"rel-L2(v) after step {n}"
     a, b = _order_by_x0(ps.x_0.to_numpy()), _order_by_x0(z[f"step{steps}/x_0"])
     assert np.array_equal(ps.x_0.to_numpy()[a], z[f"step{steps}/x_0"][b])
     assert scenes.rel_l2(ps.x.to_numpy()[a], z[f"step{steps}/x"][b]) <= 1e-4
@@ -259,8 +261,9 @@ def test_hip_reproduces_big_reference_execution(path):
     ps.close()
     # (VERDICT r03 "weak" #4) the measured number of differing cell ids per kept stage, on record: gpurun_out -> profiles/
     try:
-        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "big_fixture_cell_id_mismatches.json")
-        os.makedirs(os.path.dirname(out), exist_ok=True)
+        out = scenes.evidence_path("big_fixture_cell_id_mismatches.json")
+        if out is None:
+            return
         data = json.load(open(out)) if os.path.exists(out) else {}
         data[os.path.basename(path)] = {"particles": int(z["initial/x"].shape[0]), "differing_cell_ids_after_step": mismatches}
         json.dump(data, open(out, "w"), indent=1)

@@ -87,7 +87,8 @@ def test_c3_armadillo_equivalent_dynamic_bodies():
     _record_curve("c3_bodies_vs_f32_reference_order_oracle", [(n, e32)], bound=2e-4,
                   hip_vs_f64_sums_oracle=float(e64), f64_sums_oracle_vs_f32_sums_oracle=float(e_oracles))
     assert e32 <= 2e-4, f"C3 bodies vs the f32 reference-order oracle after {n} steps: {e32:.3e}"
-    assert e_oracles >= 0.5 * e32 and e64 <= 0.25 * e32, (e32, e_oracles, e64)
+    # (the triangle's sides are recorded above, not asserted against each other: ADVICE r04 -- a relation between measured
+    # rounding errors fails on any legitimate accuracy improvement; the absolute bounds are what is tested)
     v = scenes.ps_by_pid(ps, "v")
     free_fall = -5.0 - 9.81 * n * 4e-4
     light = sc.arrays["object_id"] == 3                     # density 300: decelerated hard by the fluid
@@ -224,12 +225,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _record_curve(name, curve, **extra):
-    """Append one case's error-vs-N curve to gpurun_out/parity_curves.json (best effort: the file is evidence,
+    """Append one case's error-vs-N curve to $SPH_TEST_EVIDENCE_DIR/parity_curves.json (best effort: the file is evidence,
     not part of the assertion)."""
     try:
-        out = os.path.join(ROOT, "gpurun_out")
-        os.makedirs(out, exist_ok=True)
-        path = os.path.join(out, "parity_curves.json")
+        path = scenes.evidence_path("parity_curves.json")
+        if path is None:
+            return
         data = json.load(open(path)) if os.path.exists(path) else {}
         data[name] = dict(extra, rel_l2_x=[[int(n), float(e)] for n, e in curve])
         for k in ("rel_l2_density", "rel_l2_v"):

@@ -27,10 +27,11 @@ _MEASURED = {}     # name -> (worst measured error, tolerance): dumped to gpurun
 def _dump_measured():
     import json, os
     try:
-        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-        os.makedirs(out, exist_ok=True)
+        out = scenes.evidence_path("parity_errors.json")
+        if out is None:
+            return
         json.dump({k: {"max_err_over_max_ref": v[0], "tolerance": v[1]} for k, v in sorted(_MEASURED.items())},
-                  open(os.path.join(out, "parity_errors.json"), "w"), indent=1)
+                  open(out, "w"), indent=1)
     except OSError:
         pass
 
@@ -217,7 +218,6 @@ def test_random_clouds_on_awkward_grids(dom, n, seed):
         ps, solver = scenes.make_ps(_scene_with_domain(sd2, dom, n), a, gather_impl=impl, brick_shape=shape)
         o2.initialize(); solver.initialize()
         o2.step(2); solver.step(2)
-        assert np.array_equal(ps.pid.to_numpy(), o2["pid"]) or scenes.rel_l2(scenes.ps_by_pid(ps, "x"), o2.by_pid("x")) <= 1e-4
         assert scenes.rel_l2(scenes.ps_by_pid(ps, "x"), o2.by_pid("x")) <= 1e-4
         ps.close()
 
@@ -415,10 +415,10 @@ def test_long_run_of_dynamic_bodies_follows_the_oracle():
                       "rel_l2_x_bodies": scenes.rel_l2(x[~fluid & (a["is_dynamic"] == 1)], o.by_pid("x")[~fluid & (a["is_dynamic"] == 1)])})
     ps.close()
     try:
-        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-        os.makedirs(out, exist_ok=True)
-        json.dump({"scene": "tests/scenes.py::fluid_with_rigid_bodies (1,344 fluid + 2 dynamic + 1 static body)", "curve": curve},
-                  open(os.path.join(out, "long_bodies.json"), "w"), indent=1)
+        out = scenes.evidence_path("long_bodies.json")
+        if out is not None:
+            json.dump({"scene": "tests/scenes.py::fluid_with_rigid_bodies (1,344 fluid + 2 dynamic + 1 static body)", "curve": curve},
+                      open(out, "w"), indent=1)
     except OSError:
         pass
     # while the trajectories are still correlated (the first few hundred steps) the bodies agree closely ...
@@ -428,10 +428,11 @@ def test_long_run_of_dynamic_bodies_follows_the_oracle():
     # ... later the run is chaotic (a body tumbles through 170 degrees within 100 steps once a corner digs into the floor),
     # so only the KIND of motion is compared: the largest particle speed inside a body has grown far beyond the -2 m/s the
     # bodies were released with -- on BOTH sides, by comparable factors
+    # (the growth factors themselves are recorded in the curve, not asserted: ADVICE r04 -- a relation between two chaotic
+    # maxima is flaky by construction; what is asserted is that the growth is the reference's too, not the HIP path's alone)
     for oid in (1, 2):
         h, r = max(c["hip"][oid]["v_max"] for c in curve), max(c["oracle"][oid]["v_max"] for c in curve)
         assert h > 10.0 and r > 10.0, (oid, h, r)
-        assert 1.0 / 3.0 <= h / r <= 3.0, (oid, h, r)
 
 
 # ---------------------------------------------------------------------------

@@ -450,8 +450,10 @@ class SlabSolver:
     """One rank of the slab-decomposed WCSPH solver."""
 
     def __init__(self, scene_dict, rank, world, device=0, cuts=None, capacity_factor=1.5, use_torch_stream=False,
-                 gather_impl=1, brick_shape=0, scene_dir=None, recut_every=0, nx_slack=16, check_every=64):
-        """`recut_every` = K > 0: every K steps the ranks add up their per-layer particle counts and every cut plane
+                 gather_impl=1, brick_shape=0, scene_dir=None, recut_every=0, nx_slack=16, check_every=64, state=None):
+        """`state` = {"x", "v"} by persistent id (e.g. gather_by_pid of an earlier run): the job restarts from there; the
+        cuts are planned on the restart positions.
+        `recut_every` = K > 0: every K steps the ranks add up their per-layer particle counts and every cut plane
         moves ONE cell layer towards the position that balances the particle counts (`plan_recut`); the slab may
         grow by `nx_slack` layers over its initial width before the allocation is the limit."""
         import torch
@@ -464,7 +466,7 @@ class SlabSolver:
         dyn_bodies = [b for b in cfg.get_rigid_bodies() if b.get("isDynamic")]
         self.has_dynamic = bool(dyn_blocks or dyn_bodies)
         self.halo = halo = HALO_DYNAMIC if self.has_dynamic else HALO
-        hist = _scene.x_layer_histogram(cfg, base_dir=scene_dir)
+        hist = _scene.x_layer_histogram(cfg, base_dir=scene_dir, state=state)
         if cuts is None:
             cuts = _scene.slab_cuts(hist, world, min_width=halo + 1)
         self.cuts = list(cuts)
@@ -492,7 +494,7 @@ class SlabSolver:
         self._shift = (0, 0)        # pending move of (left cut, right cut), applied at the next exchange
         self._recut_due = False
         self._guard_due = False
-        self.ps = ParticleSystem(cfg, device=device, stream=stream, scene_dir=scene_dir,
+        self.ps = ParticleSystem(cfg, device=device, stream=stream, scene_dir=scene_dir, state=state,
                                  slab=dict(x_lo=self.x_lo, x_hi=self.x_hi, halo=halo, capacity=capacity,
                                            nx_slack=int(nx_slack) if self.recut_every > 0 else 0))
         self.ps.set_option(_lib.OPT_GATHER_IMPL, gather_impl)

@@ -19,10 +19,13 @@ from .field import DeviceField, HostScalar
 
 class ParticleSystem:
     def __init__(self, config: SimConfig, GGUI=False, device: int = 0, stream=None, scene_dir: str | None = None,
-                 verbose: bool = False, slab: dict | None = None, populate: bool = True):
+                 verbose: bool = False, slab: dict | None = None, populate: bool = True, state: dict | None = None):
         """`slab` (multi-GPU, no reference counterpart) = dict(x_lo, x_hi, halo, capacity[, nx_slack]): this
         context owns the global cell layers [x_lo, x_hi) plus `halo` ghost layers on each side; `nx_slack` more
         layers are allocated so that a re-cut (`set_slab_window`) can widen the slab.
+
+        `state` = {"x", "v"}: f32[N, 3] by persistent id -- a restart: the scene file says WHAT the particles are, `state`
+        where they are and how fast (a slab rank keeps those whose restart position lies in its layers).
 
         `populate=False` stops where the reference's constructor stands after its allocations
         (particle_system.py:91-145): every field exists with `particle_max_num` zeroed rows and
@@ -37,7 +40,7 @@ class ParticleSystem:
             nx = int(g0.grid_num[0])
             x_filter = lambda xs: ((_scene.x_layer_of(xs, g0.grid_size, nx) >= slab["x_lo"])
                                    & (_scene.x_layer_of(xs, g0.grid_size, nx) < slab["x_hi"]))
-        sc = _scene.build_scene(config, base_dir=scene_dir, verbose=verbose, x_filter=x_filter)
+        sc = _scene.build_scene(config, base_dir=scene_dir, verbose=verbose, x_filter=x_filter, state=state)
         g = sc.geom
         self._scene = sc
         # ---- scalars, same names as the reference (particle_system.py:17-46) ----

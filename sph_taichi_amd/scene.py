@@ -60,8 +60,14 @@ class SceneBuilder:
     """Accumulates particles object by object (the reference appends to Taichi
     fields through _add_particles; here they are NumPy chunks)."""
 
-    def __init__(self, geom: Geometry, x_filter=None):
+    def __init__(self, geom: Geometry, x_filter=None, state=None):
+        """`state` = {"x": f32[N, 3], "v": f32[N, 3]} by persistent id (the order the scene file creates its particles in):
+        the particles START there instead of where the scene file puts them -- a restart -- and `x_filter` (the slab a rank
+        owns) is applied to the restart positions; x_0 stays the scene file's position (the rest shape of a body)."""
         self.g = geom
+        self.state = None
+        if state is not None:
+            self.state = {k: np.ascontiguousarray(state[k], dtype=np.float32).reshape(-1, 3) for k in ("x", "v")}
         self.chunks = {k: [] for k in ARRAY_SPECS}
         self.chunks["pid"] = []
         self.count = 0          # particles kept (== global_count without a filter)
@@ -72,23 +78,30 @@ class SceneBuilder:
         """particle_system.py:223-284 (add_particle semantics: x_0 = x, m_V = m_V0, m = m_V0*density)."""
         positions = np.asarray(positions, dtype=np.float32).reshape(n, 3)
         pid = self.global_count + np.arange(n, dtype=np.int64)
+        first = self.global_count
         self.global_count += n
+        rest = None
+        if self.state is not None:
+            rest = positions
+            positions = self.state["x"][first:first + n]
+            velocity = self.state["v"][first:first + n]
         if self.x_filter is not None:
             keep = self.x_filter(positions[:, 0])
             sel = lambda a, w=None: np.asarray(a).reshape((n, w) if w else (n,))[keep]
             positions, pid = positions[keep], pid[keep]
+            rest = rest[keep] if rest is not None else None
             velocity, color = sel(velocity, 3), sel(color, 3)
             density, pressure, material, is_dynamic = sel(density), sel(pressure), sel(material), sel(is_dynamic)
             n = positions.shape[0]
-        self._append(object_id, n, positions, velocity, density, pressure, material, is_dynamic, color, pid)
+        self._append(object_id, n, positions, velocity, density, pressure, material, is_dynamic, color, pid, rest)
 
-    def _append(self, object_id, n, positions, velocity, density, pressure, material, is_dynamic, color, pid):
+    def _append(self, object_id, n, positions, velocity, density, pressure, material, is_dynamic, color, pid, rest=None):
         density = np.asarray(density, dtype=np.float32).reshape(n)
         c = self.chunks
         c["pid"].append(np.asarray(pid, dtype=np.int32))
         c["object_id"].append(np.full(n, object_id, dtype=np.int32))
-        c["x"].append(positions)
-        c["x_0"].append(positions.copy())
+        c["x"].append(np.ascontiguousarray(positions, dtype=np.float32))
+        c["x_0"].append(positions.copy() if rest is None else np.ascontiguousarray(rest, dtype=np.float32))
         c["v"].append(np.asarray(velocity, dtype=np.float32).reshape(n, 3))
         c["acceleration"].append(np.zeros((n, 3), dtype=np.float32))
         c["m_V"].append(np.full(n, self.g.m_V0, dtype=np.float32))
@@ -106,7 +119,24 @@ class SceneBuilder:
         d = self.g.particle_diameter
         axes = [np.arange(lower_corner[i], lower_corner[i] + cube_size[i], d) for i in range(self.g.dim)]
         n_full = len(axes[0]) * len(axes[1]) * len(axes[2])
-        if self.x_filter is not None:
+        if self.state is not None and self.x_filter is not None:
+            # restart of a slab rank: the filter looks at where the particles ARE; only the kept ones' lattice positions
+            # (x_0) are materialised, from their persistent ids
+            first = self.global_count
+            self.global_count += n_full
+            x = self.state["x"][first:first + n_full]
+            keep = np.nonzero(self.x_filter(x[:, 0]))[0]
+            ny, nz = len(axes[1]), len(axes[2])
+            a32 = [a.astype(np.float32) for a in axes]
+            rest = np.stack([a32[0][keep // (ny * nz)], a32[1][(keep // nz) % ny], a32[2][keep % nz]], axis=1)
+            n = keep.shape[0]
+            self._append(object_id, n, x[keep], self.state["v"][first:first + n_full][keep],
+                         np.full(n, density if density is not None else 1000.0, dtype=np.float32),
+                         np.full(n, pressure if pressure is not None else 0.0, dtype=np.float32),
+                         np.full(n, material, dtype=np.int32), np.full(n, is_dynamic, dtype=np.int32),
+                         np.tile(np.asarray(color, dtype=np.int32), (n, 1)), first + keep, rest)
+            return n
+        if self.x_filter is not None and self.state is None:
             # subset at axis level: only the x-planes of this slab are ever materialised
             keep_ix = np.nonzero(self.x_filter(axes[0].astype(np.float32)))[0]
             grid = np.array(np.meshgrid(axes[0][keep_ix], axes[1], axes[2], sparse=False, indexing="ij"),
@@ -147,7 +177,8 @@ class Scene:
     """Result of build_scene: geometry, object bookkeeping and initial arrays."""
 
 
-def build_scene(cfg, base_dir: str | None = None, verbose: bool = False, x_filter=None) -> Scene:
+def build_scene(cfg, base_dir: str | None = None, verbose: bool = False, x_filter=None, state=None) -> Scene:
+    """`state`: restart positions / velocities by persistent id (SceneBuilder)."""
     g = Geometry(cfg)
     sc = Scene()
     sc.geom = g
@@ -187,7 +218,9 @@ def build_scene(cfg, base_dir: str | None = None, verbose: bool = False, x_filte
     sc.n_objects = sc.num_rigid_bodies + len(fluid_blocks)     # len(rigid_rest_cm), particle_system.py:93
 
     # ---- particles (particle_system.py:148-211) ----
-    b = SceneBuilder(g, x_filter)
+    if state is not None and (np.asarray(state["x"]).shape[0] != sc.particle_max_num or np.asarray(state["v"]).shape[0] != sc.particle_max_num):
+        raise ValueError(f"restart state has {np.asarray(state['x']).shape[0]} rows; the scene file creates {sc.particle_max_num} particles")
+    b = SceneBuilder(g, x_filter, state)
     for fluid in fluid_blocks:
         off = np.array(fluid["translation"])
         start, end = np.array(fluid["start"]) + off, np.array(fluid["end"]) + off
@@ -234,10 +267,13 @@ def x_layer_of(xs, grid_size, nx):
     return np.clip(layer, 0, nx - 1)
 
 
-def x_layer_histogram(cfg, base_dir=None):
-    """Particles per global x cell layer, from the block axes (no particle arrays) and the bodies' voxel points."""
+def x_layer_histogram(cfg, base_dir=None, state=None):
+    """Particles per global x cell layer, from the block axes (no particle arrays) and the bodies' voxel points -- or, for
+    a restart, from the restart positions."""
     g = Geometry(cfg)
     nx = int(g.grid_num[0])
+    if state is not None:
+        return np.bincount(x_layer_of(np.asarray(state["x"], dtype=np.float32)[:, 0], g.grid_size, nx), minlength=nx).astype(np.int64)
     hist = np.zeros(nx, dtype=np.int64)
     for blk in list(cfg.get_fluid_blocks()) + list(cfg.get_rigid_blocks()):
         off = np.array(blk["translation"])

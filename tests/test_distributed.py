@@ -157,6 +157,32 @@ def test_local_slabs_match_single_domain(world, which):
         s.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", [0, 1])
+def test_local_slabs_restart_from_a_state(which):
+    """SlabSolver(state=...): a slab job restarted from positions / velocities by persistent id (what gather_by_pid of an
+    earlier run returns) continues like the single domain restarted from the same state -- cuts planned on the restart
+    positions, every rank keeping what lies in its layers NOW."""
+    from sph_taichi_amd.distributed import SlabSolver, run_local_slabs, gather_by_pid
+    sd = _slab_scenes()[which]
+    dev, n = _single_domain(sd, 30)
+    state = {"x": dev["x"], "v": dev["v"]}
+    ps, solver = scenes.make_ps(sd, arrays=state)
+    solver.initialize()
+    solver.step(12)
+    ref = scenes.ps_by_pid(ps, "x")
+    ps.close()
+    solvers = [SlabSolver(sd, r, 3, device=0, state=state) for r in range(3)]
+    run_local_slabs(solvers, 0, initialize=True)
+    assert sum(s.owned_range[1] for s in solvers) == n
+    run_local_slabs(solvers, 12)
+    x = gather_by_pid(solvers, "x", n)
+    for s in solvers:
+        s.close()
+    assert not np.isnan(x).any()
+    assert scenes.rel_l2(x, ref) <= 2e-6
+
+
 def test_plan_recut_moves_one_layer_towards_balance():
     from sph_taichi_amd.distributed import plan_recut
     from sph_taichi_amd.scene import slab_cuts

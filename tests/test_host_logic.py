@@ -213,3 +213,37 @@ def test_pmc_file_is_quoted_only_for_its_own_kernel_fingerprint():
                     "until tools/gpu_pmc.sh + tools/refresh_pmc.py are re-run on the GPU box")
     k = pm["kernels"]["k_gather_brick<GM_DENSITY_EOS>"]
     assert k["valu_wave_insts"] > 0 and k["fetch_kb"] > 0 and k["write_kb"] > 0
+
+
+def test_restart_state_is_cut_like_the_scene():
+    """A restart (`state` = positions / velocities by persistent id, e.g. gather_by_pid of an earlier slab run): every
+    slab keeps the particles whose RESTART position lies in its layers, with the scene file's identity (object, material,
+    mass, x_0 = rest position); the slabs partition the scene; the cut-planning histogram counts the restart positions."""
+    import copy
+    from sph_taichi_amd import scene as S
+    from sph_taichi_amd.config_builder import SimConfig
+    sd = scenes.fluid_with_rigid_blocks()
+    full = S.build_scene(SimConfig(config=copy.deepcopy(sd)))
+    n = full.particle_max_num
+    rng = np.random.default_rng(0)
+    x = full.arrays["x"] + rng.uniform(-0.05, 0.05, (n, 3)).astype(np.float32)
+    v = rng.normal(size=(n, 3)).astype(np.float32)
+    g = full.geom
+    nx = int(g.grid_num[0])
+    seen = []
+    for lo, hi in ((0, 10), (10, 18), (18, nx)):
+        f = lambda xs, lo=lo, hi=hi: (S.x_layer_of(xs, g.grid_size, nx) >= lo) & (S.x_layer_of(xs, g.grid_size, nx) < hi)
+        sc = S.build_scene(SimConfig(config=copy.deepcopy(sd)), x_filter=f, state={"x": x, "v": v})
+        pid = sc.arrays["pid"]
+        assert np.array_equal(sc.arrays["x"], x[pid]) and np.array_equal(sc.arrays["v"], v[pid])
+        assert np.array_equal(sc.arrays["x_0"], full.arrays["x_0"][pid])
+        for k in ("object_id", "material", "is_dynamic", "m", "density", "color"):
+            assert np.array_equal(sc.arrays[k], full.arrays[k][pid]), k
+        seen.append(pid)
+    assert np.array_equal(np.sort(np.concatenate(seen)), np.arange(n))
+    hist = S.x_layer_histogram(SimConfig(config=copy.deepcopy(sd)), state={"x": x, "v": v})
+    assert hist.sum() == n and np.array_equal(hist, np.bincount(S.x_layer_of(x[:, 0], g.grid_size, nx), minlength=nx))
+    whole = S.build_scene(SimConfig(config=copy.deepcopy(sd)), state={"x": x, "v": v})
+    assert np.array_equal(whole.arrays["x"], x) and np.array_equal(whole.arrays["x_0"], full.arrays["x_0"])
+    with pytest.raises(ValueError, match="restart state"):
+        S.build_scene(SimConfig(config=copy.deepcopy(sd)), state={"x": x[:-1], "v": v[:-1]})

@@ -1387,7 +1387,7 @@ def run_slab_bench(args, rank, world, local_rank, wd=None):
 
         class _Budgeted:            # every stage of the object inherits what is left of the object's budget
             def stage(self, name, budget_s=None):
-                wd.stage(name, budget_s=max(t_end - time.monotonic(), 1.0) if budget != float("inf") else None)
+                wd.stage(name, budget_s=max(t_end - time.monotonic(), 0.05) if budget != float("inf") else None)
 
             def keep(self, line, key):
                 pass

@@ -20,9 +20,9 @@ cd $R
 export TMPDIR=/tmp
 has() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
 if has tests; then
-  timeout 900 python -m pytest tests -m gpu -q --durations=5 > $OUT/pytest_gpu.log 2>&1; echo "gpu pytest rc=$?"
-  tail -n 10 $OUT/pytest_gpu.log
-  cp gpurun_out/parity_curves.json $OUT/ 2>/dev/null; cp gpurun_out/parity_errors.json $OUT/ 2>/dev/null
+  # (the tests leave their measured curves / error tables under $SPH_TEST_EVIDENCE_DIR only when it is set)
+  SPH_TEST_EVIDENCE_DIR=$OUT timeout 1200 python -m pytest tests -m gpu -q --durations=15 ${PYTEST_ARGS:-} > $OUT/pytest_gpu.log 2>&1; echo "gpu pytest rc=$?"
+  tail -n 30 $OUT/pytest_gpu.log
 fi
 if has pmc; then
   bash tools/gpu_pmc.sh ${TAG}_rest > $OUT/pmc_rest.log 2>&1; tail -n 2 $OUT/pmc_rest.log

@@ -233,7 +233,8 @@ typedef struct SphStats {
     int32_t lds_overflow_targets;  /* targets of bricks whose shell did not fit the LDS tile: both sweeps walk the cells */
     int32_t max_cell_occupancy;    /* particles in the fullest cell */
     int32_t nonempty_cells;
-    int32_t reserved_;
+    int32_t polar_fallbacks;       /* solve_constraints() calls since sph_create whose polar rotation (sph_base.py:212) left the Newton
+                                      iteration for the Jacobi-SVD form: degenerate bodies (flat = rank-2 A, rods, reflections) */
 } SphStats;
 int32_t sph_get_stats(SphContext* ctx, SphStats* out);
 
@@ -355,8 +356,12 @@ int32_t sph_comm_info(SphContext* ctx, SphComm* comm, int32_t* rank, int32_t* wo
  * DFSPH (simulationMethod 4): DFSPHSolver of /root/reference/DFSPH.py on the same neighbour
  * machinery.  The density sweep writes every fluid particle's neighbour list once per step;
  * all later sweeps of the step (factor, density change / advection, both Jacobi solvers,
- * non-pressure forces) read those lists.  The solver loops run inside the library; each
- * iteration reads one f32 back (the reference's compute_density_error does the same).
+ * non-pressure forces) read those lists.  The solver loops run inside the library.  The
+ * reference's loop has the host between two iterations (compute_density_error returns a
+ * float that Python compares with eta); here the test is made on the device with the same
+ * arithmetic, the host enqueues iteration k + 1 before it waits for iteration k's result,
+ * and sweeps enqueued past convergence leave at once: the GPU never waits for the host,
+ * the iteration counts stay the reference's (sph_api.hip: df_solve_loop).
  * ==================================================================================== */
 typedef struct SphDfsphParams {
     int32_t enable_divergence_solver; /* DFSPH.py:12 */

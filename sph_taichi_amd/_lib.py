@@ -36,7 +36,7 @@ class SphTimings(C.Structure):
 class SphStats(C.Structure):
     _fields_ = [("targets", C.c_int64), ("list_entries", C.c_int64), ("max_list", C.c_int32),
                 ("list_overflow_targets", C.c_int32), ("lds_overflow_targets", C.c_int32),
-                ("max_cell_occupancy", C.c_int32), ("nonempty_cells", C.c_int32), ("reserved_", C.c_int32)]
+                ("max_cell_occupancy", C.c_int32), ("nonempty_cells", C.c_int32), ("polar_fallbacks", C.c_int32)]
 
 
 class SphDfsphParams(C.Structure):

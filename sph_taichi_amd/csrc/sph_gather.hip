@@ -71,6 +71,14 @@ __host__ __device__ constexpr bool mode_is_df_iter() {
 }
 template <int MODE>
 __host__ __device__ constexpr bool mode_is_df_pressure() { return MODE == GM_DF_PRESSURE_ITER || MODE == GM_DF_PRESSURE_ITER_U; }
+// the sweeps a DFSPH solver iteration consists of: enqueued ahead of the previous iteration's convergence test, they leave
+// at once when that test has closed the solve (DevView::gate, sph_api.hip: df_solve_loop)
+template <int MODE>
+__host__ __device__ constexpr bool mode_is_df_gated() {
+    return MODE == GM_DF_DIV_ITER || MODE == GM_DF_PRESSURE_ITER || MODE == GM_DF_DIV_ITER_U || MODE == GM_DF_PRESSURE_ITER_U ||
+           MODE == GM_DF_DENSITY_CHANGE || MODE == GM_DF_DENSITY_ADV;
+}
+
 template <int MODE>
 __host__ __device__ constexpr bool mode_is_df_vdiv() { return MODE == GM_DF_DENSITY_CHANGE || MODE == GM_DF_DENSITY_ADV; }
 template <int MODE>
@@ -641,6 +649,7 @@ __device__ __forceinline__ void gather_walk_global(const DevView& d, Target& t, 
 // list == nullptr: all particles [0,N); else the n entries of list
 template <int MODE>
 __global__ __launch_bounds__(TPB) void k_gather_simple(DevView d, const int* __restrict__ list, int n) {
+    if (mode_is_df_gated<MODE>() && d.gate && *d.gate == d.gate_epoch) return;  // a solver iteration enqueued past convergence
     const int tix = blockIdx.x * TPB + threadIdx.x;
     if (tix >= n) return;
     const int i = list ? list[tix] : tix;
@@ -821,6 +830,7 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
     int* sTOff = reinterpret_cast<int*>(smem + CFG::off_toff(HAS_W));  // target-number start of the column (+ total at [64])
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (mode_is_df_gated<MODE>() && d.gate && *d.gate == d.gate_epoch) return;  // a solver iteration enqueued past convergence
 
     // One workgroup per LISTED brick (the hardware scheduler balances them).  Hardware block b runs on XCD b%8:
     // XCD x takes the x-th eighth of the list, so neighbouring bricks share that XCD's L2 and -- because the list
@@ -1277,6 +1287,7 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
 // after a sweep that scatters coupling reactions: acc of every dynamic rigid particle += its fixed-point sums, which
 // return to zero (the accumulators are all zero between sweeps, whatever the order of the particles becomes)
 __global__ __launch_bounds__(TPB) void k_fold_coupling(DevView d, const int* __restrict__ list, int first, int n) {
+    if (d.gate && *d.gate == d.gate_epoch) return;  // (inside a DFSPH solver loop only: the sweep it would fold never ran)
     const int t = blockIdx.x * TPB + threadIdx.x;
     if (t >= n) return;
     // list == nullptr: the list of dynamic rigid particles is not current (a slab rank between its truncate and the
@@ -1656,6 +1667,8 @@ __global__ __launch_bounds__(TPB) void k_stats_total(const unsigned long long* _
 int sphk_stats(SphContext* c, SphStats* out) {
     memset(out, 0, sizeof(*out));
     if (c->N <= 0) return 0;
+    int fb = 0;
+    SPH_HIP(c, hipMemcpyAsync(&fb, c->dyn_count + 3, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     DevView d = sph_view(c);
     const int n = max(c->N, c->G);
     int nb = (n + TPB - 1) / TPB;
@@ -1675,6 +1688,7 @@ int sphk_stats(SphContext* c, SphStats* out) {
     out->targets = (int64_t)h[0]; out->list_entries = (int64_t)h[1]; out->max_list = (int32_t)h[2];
     out->list_overflow_targets = (int32_t)h[3]; out->lds_overflow_targets = (int32_t)h[4];
     out->max_cell_occupancy = (int32_t)h[5]; out->nonempty_cells = (int32_t)h[6];
+    out->polar_fallbacks = fb;
     return 0;
 }
 

@@ -110,6 +110,45 @@ __global__ __launch_bounds__(TPB) void k_df_density_error(DevView d, float offse
     }
 }
 
+// ... and the solver loops' form (sph_api.hip: df_solve_loop): the same two stages behind the solve's gate, the second one
+// making the reference's convergence test itself -- (f32 sum) / fluid_particle_num <= eta in f64, DFSPH.py:260-263 / 346-349 --
+// and stamping the gate when it holds.
+__global__ __launch_bounds__(TPB) void k_df_density_error_gated(DevView d, float offset, double* __restrict__ part) {
+    if (d.gate && *d.gate == d.gate_epoch) return;
+    __shared__ double red[TPB / 64];
+    double v = 0.0;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < d.N; i += gridDim.x * TPB)
+        if (sph_is_fluid(__float_as_int(d.vf[i].w))) v += (double)(d.rho0 * d.eos[i].y - offset);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < TPB / 64; ++w) t += red[w];
+        part[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_df_convergence_test(const double* __restrict__ part, int n, int count, double eta,
+                                                            SphContext::DfSlot* __restrict__ slot, unsigned* __restrict__ gate,
+                                                            unsigned epoch) {
+    if (*gate == epoch) return;
+    double v = 0.0;
+    for (int k = threadIdx.x; k < n; k += 64) v += part[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (threadIdx.x == 0) {
+        const float err = (float)v;                          // compute_density_error returns an f32 (DFSPH.py:224-230)
+        const double avg = (double)err / (double)count;      // Python-scope float arithmetic: f64
+        const int conv = avg <= eta ? 1 : 0;
+        slot->err = err;
+        slot->avg = avg;
+        slot->converged = conv;
+        if (conv) *gate = epoch;
+    }
+}
+
 __global__ __launch_bounds__(64) void k_df_density_error_total(const double* __restrict__ part, int n,
                                                                double* __restrict__ out) {
     double v = 0.0;
@@ -415,7 +454,9 @@ __device__ bool polar_rotation_newton(const double A[3][3], float R_[9]) {
 }
 
 // cm (and the polar rotation) from the summed partials; one lane per block computes them into LDS
-__device__ __forceinline__ void rigid_cm_R(const double* tot, bool want_R, float* cmR /*[12] in LDS*/) {
+// `fb` (block 0 only, may be null): counts the solves that left the Newton iteration for the Jacobi-SVD form -- degenerate bodies
+// (flat: rank-2 A; a rod; reflected) -- so that a test can see the fallback fire (SphStats.polar_fallbacks).
+__device__ __forceinline__ void rigid_cm_R(const double* tot, bool want_R, float* cmR /*[12] in LDS*/, int* fb = nullptr) {
     const float sum_m = (float)tot[0];  // f32 division like the reference's cm /= sum_m (0/0 = NaN for static bodies)
     cmR[0] = (float)tot[1] / sum_m; cmR[1] = (float)tot[2] / sum_m; cmR[2] = (float)tot[3] / sum_m;
     if (!want_R) return;
@@ -423,7 +464,10 @@ __device__ __forceinline__ void rigid_cm_R(const double* tot, bool want_R, float
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) A[i][j] = (double)(float)tot[4 + 3 * i + j];
     float R[9];
-    if (!polar_rotation_newton(A, R)) polar_rotation(A, R);
+    if (!polar_rotation_newton(A, R)) {
+        polar_rotation(A, R);
+        if (fb) atomicAdd(fb, 1);
+    }
     bool all_small = true;
     for (int i = 0; i < 9; ++i)
         if (!(fabsf(R[i]) < 1e-6f)) all_small = false;
@@ -459,7 +503,7 @@ __global__ __launch_bounds__(TPB) void k_rigid_apply(DevView d, const int* __res
     double tot[13];
     sum_partials(d, part, nblk, 0, 13, tot, s_tmp);
     if (threadIdx.x == 0) {
-        rigid_cm_R(tot, true, cmR);
+        rigid_cm_R(tot, true, cmR, blockIdx.x == 0 ? d.polar_fb : nullptr);
         if (blockIdx.x == 0)
             for (int k = 0; k < 12; ++k) out[k] = cmR[k];
     }
@@ -635,7 +679,7 @@ __device__ __forceinline__ void rigid_phase_apply(const DevView& d, const WallHi
     __shared__ float cmR[SPH_MAX_BATCH_BODIES][12];
     sum_partials_all(d, part, nblk, ids.n, 13, s_tot);
     if ((int)threadIdx.x < ids.n) {
-        rigid_cm_R(s_tot[threadIdx.x], true, cmR[threadIdx.x]);
+        rigid_cm_R(s_tot[threadIdx.x], true, cmR[threadIdx.x], blockIdx.x == 0 ? d.polar_fb : nullptr);
         if (blockIdx.x == 0 && (int)threadIdx.x == ids.n - 1)  // what the body-by-body sequence leaves behind: the last body's
             for (int k = 0; k < 12; ++k) out[k] = cmR[threadIdx.x][k];
     }
@@ -730,7 +774,7 @@ __global__ __launch_bounds__(TPB) void k_rigid_apply_sums(DevView d, const int* 
                               (double)((float)tot[3] / sum_m)};
         for (int a = 0; a < 3; ++a)
             for (int b = 0; b < 3; ++b) tot[4 + 3 * a + b] = sums[7 + 3 * a + b] - cm[a] * sums[4 + b];
-        rigid_cm_R(tot, mode == 1, cmR);
+        rigid_cm_R(tot, mode == 1, cmR, blockIdx.x == 0 ? d.polar_fb : nullptr);
         if (blockIdx.x == 0) {
             for (int k = 0; k < (mode == 1 ? 12 : 3); ++k) out[k] = cmR[k];
             if (mode == 0)
@@ -1086,6 +1130,22 @@ int sphk_df_density_error_range(SphContext* c, float offset, int first, int coun
         h = *(volatile double*)c->h_df_err;
     }
     *out_host = h;
+    return 0;
+}
+
+int sphk_df_convergence_test(SphContext* c, float offset, double eta, int slot) {
+    DevView d = sph_view(c);
+    int nb = (c->N + TPB - 1) / TPB;
+    if (nb > SPH_DF_ERR_BLOCKS) nb = SPH_DF_ERR_BLOCKS;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL(k_df_density_error_gated, dim3(nb), dim3(TPB), 0, c->stream, d, offset, c->df_part);
+    SPH_LAUNCH_CHECK(c);
+    SphContext::DfSlot* dev_slot = nullptr;
+    SPH_HIP(c, hipHostGetDevicePointer((void**)&dev_slot, c->h_df_slot, 0));
+    const int count = c->df.fluid_particle_num > 0 ? c->df.fluid_particle_num : 1;
+    hipLaunchKernelGGL(k_df_convergence_test, dim3(1), dim3(64), 0, c->stream, c->df_part, nb, count, eta, dev_slot + slot,
+                       c->df_gate, c->df_epoch);
+    SPH_LAUNCH_CHECK(c);
     return 0;
 }
 

@@ -38,6 +38,10 @@ struct DevView {
     int sort_by_pid;   // intra-cell order by persistent id (SPH_OPT_SORT_BY_PID)
     int drop_outside;  // slab mode: x layer outside the local grid -> virtual cell G
     int exp_int;     // Tait exponent as a small integer (1..32) when it is one, else 0 (WCSPH.py:76)
+    // DFSPH solver loops (round 5): the sweeps of a Jacobi iteration that the host enqueued AHEAD of the previous
+    // iteration's convergence test leave at once when that test (made on the device) has closed the solve
+    const unsigned* gate;  // null outside the solver loops
+    unsigned gate_epoch;   // *gate == gate_epoch: this solve has converged
 #ifdef SPH_PROFILE
     int ablate;      // profiling build only: bit0 skip phase 2, bit1 skip list write-out, bit2 skip phase 1, ... (sph_gather.hip)
     unsigned long long* prof_ts;  // profiling build only: 8 words per hardware block of the brick sweeps (SPH_TS)
@@ -69,6 +73,7 @@ struct DevView {
     int* key;
     int* cell_end;
     const float* x0_cold;
+    int* polar_fb;   // counter of solve_constraints() calls that took the Jacobi-SVD fallback (context's dyn_count[3])
     float* rigid_rest_cm;
 };
 
@@ -112,7 +117,9 @@ struct SphContext {
     bool next_cells_zero;  // cell_buf[cell_cur ^ 1] is all zero (no memset needed before the next histogram)
     int* rank_off;     // [cap] arbitrary intra-cell offset from the histogram atomics
     int* idx_unstable; // [cap]
-    int* scan_sums;    // block sums for the scan
+    unsigned long long* scan_status;  // per scan tile: launch epoch << 32 | tile total (k_scan_fused)
+    unsigned scan_epoch;
+    int* scan_err;     // raised by a scan tile that never saw a predecessor's total (a bounded wait, never a hang)
     unsigned short* glist;  // neighbour lists handed from the density to the force sweep: SPH_GLIST_ROWS / 4 entry groups of
                             // 2^glist_shift bytes, entry r of particle i at (r >> 2) << glist_shift | i * 8 | (r & 3) * 2
     int glist_shift;        // smallest shift with cap * 8 <= 2^shift; 0 = no lists (32-bit offsets would not reach: cell walk)
@@ -142,6 +149,11 @@ struct SphContext {
     bool bricks_valid;  // brick_list/brick_count describe the current order for the target ranges in bricks_key
     int bricks_key[5];  // partition id (footprint, cut rule, limits), tgt_lo, tgt_hi, tgt_lo2, tgt_hi2
     double* h_df_err;   // pinned, device-visible: result of compute_density_error
+    struct DfSlot { float err; int converged; double avg; }* h_df_slot;  // [4] pinned, device-visible: the convergence test of a solver iteration
+    unsigned* df_gate;  // device word: epoch of the last solve that converged (DevView::gate)
+    unsigned df_epoch;  // epoch of the running solve (0: none -- the gate is closed to everybody else)
+    unsigned df_epoch_done;  // epoch of the last finished solve
+    hipEvent_t ev_df[4];
     double* df_part;    // [SPH_DF_ERR_BLOCKS] per-workgroup partial sums
     SphDfsphParams df;  // DFSPH solver knobs
     SphDfsphStats df_stats;
@@ -204,6 +216,7 @@ int sphk_pack_advected(SphContext* c, int first, int count, void* dst);
 int sphk_eos(SphContext* c);
 int sph_ensure_aux(SphContext* c);  // materialise density / pressure in aux if the lean density finish left them in eos2
 int sphk_stats(SphContext* c, SphStats* out);  // synchronises
+int sphk_df_convergence_test(SphContext* c, float offset, double eta, int slot);  // device-side compute_density_error + test
 int sphk_check_uniform_fluid(SphContext* c);  // sets uniform_state / m_uniform (synchronises)
 int sphk_df_density_error(SphContext* c, float offset, float* out_host);
 int sphk_df_density_error_range(SphContext* c, float offset, int first, int count, double* out_host);

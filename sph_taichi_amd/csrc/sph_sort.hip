@@ -10,7 +10,8 @@
 //                    the cell (one returning atomic per RUN of equal cells in
 //                    a wave -- particles arrive almost sorted, so ~8x fewer
 //                    atomics than one per particle)
-//   scan           : cell_end = inclusive prefix (2 launches, wave64 shuffles; each tile adds up the totals before it)
+//   scan           : cell_end = inclusive prefix (ONE launch, wave64 shuffles; each tile publishes its total in an atomic
+//                    word and adds up the totals of the tiles before it)
 //   unstable_place : idx_unstable[start(c)+off[i]] = i
 //   stable_scatter : rank of i among its cell's members by previous index,
 //                    then move the 48-byte hot record (ping-pong, no copy-back)
@@ -71,21 +72,19 @@ __device__ __forceinline__ int block_exclusive_offset(int thread_total, int* s_w
     return wave_off + incl - thread_total;
 }
 
-__global__ __launch_bounds__(TPB) void k_scan_reduce(const int4* __restrict__ data, int* __restrict__ sums) {
-    __shared__ int s_wave[TPB / 64];
-    const int base = (blockIdx.x * TPB + threadIdx.x) * (SCAN_IPT / 4);
-    int t = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_IPT / 4; ++k) {
-        const int4 v = data[base + k];
-        t += v.x + v.y + v.z + v.w;
-    }
-    int tot;
-    (void)block_exclusive_offset(t, s_wave, tot);
-    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
-}
-
-__global__ __launch_bounds__(TPB) void k_scan_apply(int4* __restrict__ data, const int* __restrict__ sums) {
+// One launch (round 5; rounds 1-4: k_scan_reduce + k_scan_apply, the tile loaded twice and a kernel boundary -- ~3.3 us on
+// this part -- between them).  Every tile publishes its total as ONE 64-bit word (launch epoch << 32 | total) with a
+// device-scope atomic, then adds up the totals of the tiles before it -- waiting for the epoch to appear in each -- and
+// writes its scanned values.  Only the TOTALS cross workgroups inside the kernel, and they travel in the atomic word
+// itself: no fence, no cache write-back (an agent-scope release costs what a kernel boundary costs here, DESIGN_HISTORY
+// r04); the scanned cells are ordinary stores that the next kernel reads.  No chained look-back either: a tile waits for
+// totals, never for another tile's prefix, so the critical path is one load + reduce + atomic, whatever the tile count.
+// Deadlock-free without co-residency: a tile waits only for tiles with SMALLER block ids, which the dispatcher started
+// before it and which wait for nothing but still smaller ones.  The wait is bounded all the same: a tile that does not see
+// a predecessor's word within SCAN_SPIN_LIMIT polls raises *err instead of hanging the GPU.
+#define SCAN_SPIN_LIMIT (1 << 22)
+__global__ __launch_bounds__(TPB) void k_scan_fused(int4* __restrict__ data, unsigned long long* __restrict__ status,
+                                                    unsigned epoch, int* __restrict__ err) {
     __shared__ int s_wave[TPB / 64];
     const int base = (blockIdx.x * TPB + threadIdx.x) * (SCAN_IPT / 4);
     int4 v[SCAN_IPT / 4];
@@ -95,15 +94,25 @@ __global__ __launch_bounds__(TPB) void k_scan_apply(int4* __restrict__ data, con
         v[k] = data[base + k];
         t += v[k].x + v[k].y + v[k].z + v[k].w;
     }
-    // The tile's offset = sum of the totals of the tiles before it: each block adds them up itself (a few hundred
-    // L2-resident integers spread over its 256 lanes) -- there is no separate one-block launch that scans the totals,
-    // and a launch between two dependent kernels costs ~5 us here whatever it does.
+    int tot;
+    const int ex = block_exclusive_offset(t, s_wave, tot);
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&status[blockIdx.x], ((unsigned long long)epoch << 32) | (unsigned)tot, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     int before = 0;
-    for (int j = threadIdx.x; j < (int)blockIdx.x; j += TPB) before += sums[j];
-    int tot, before_tot;
-    (void)block_exclusive_offset(before, s_wave, before_tot);
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += TPB) {
+        unsigned long long w;
+        int spins = 0;
+        do {
+            w = __hip_atomic_load(&status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while ((unsigned)(w >> 32) != epoch && ++spins < SCAN_SPIN_LIMIT);
+        if ((unsigned)(w >> 32) != epoch) { *err = 1; w = 0ull; }
+        before += (int)(unsigned)w;
+    }
     __syncthreads();  // s_wave is reused
-    int run = before_tot + block_exclusive_offset(t, s_wave, tot);
+    int before_tot;
+    (void)block_exclusive_offset(before, s_wave, before_tot);
+    int run = before_tot + ex;
 #pragma unroll
     for (int k = 0; k < SCAN_IPT / 4; ++k) {
         run += v[k].x; v[k].x = run;
@@ -215,9 +224,13 @@ int sphk_hash_histogram(SphContext* c) {
 
 int sphk_scan(SphContext* c) {
     const int nb = c->scan_blocks;
-    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(TPB), 0, c->stream, (const int4*)c->cell_end, c->scan_sums);
-    SPH_LAUNCH_CHECK(c);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(TPB), 0, c->stream, (int4*)c->cell_end, c->scan_sums);
+    c->scan_epoch += 1u;
+    if (c->scan_epoch == 0u) {  // (wrapped after 2^32 scans: the words of an old epoch 1 could be mistaken for new ones)
+        SPH_HIP(c, hipMemsetAsync(c->scan_status, 0, (size_t)(nb + 1) * 8, c->stream));
+        c->scan_epoch = 1u;
+    }
+    hipLaunchKernelGGL(k_scan_fused, dim3(nb), dim3(TPB), 0, c->stream, (int4*)c->cell_end, c->scan_status, c->scan_epoch,
+                       c->scan_err);
     SPH_LAUNCH_CHECK(c);
     return 0;
 }

@@ -92,6 +92,49 @@ def fluid_with_rigid_bodies(obj_path, fluid_velocity=(0.0, -1.0, 0.0), body_velo
     return sd
 
 
+def degenerate_bodies(obj_path, which):
+    """Shape-matched dynamic bodies whose polar decomposition (sph_base.py:200-222, ti.polar_decompose of A = sum m p q^T) is
+    DEGENERATE, next to fluid (VERDICT r04 "missing" #6).  Returns (scene dict, state_fn): state_fn(arrays) -> {"x", "v"} is
+    the START state -- the scene file cannot say "turned against its rest shape", so the bodies' particles are moved (about
+    their own centre of mass: rigid_rest_cm is compute_com() at initialize(), sph_base.py:87-89) while x_0 keeps the shape
+    the scene file gave it:
+      "flat"   : ONE layer of voxels (cube OBJ scaled to 0.1 x 0.005 x 0.1: 36 particles, rank-2 A), tilted by 25 degrees;
+      "turned" : two boxes of 6 x 4 x 2 voxels, one started turned by 179 degrees about an oblique axis (A = R S with
+                 trace R ~ -1), one started MIRRORED through its thin axis (det A < 0: the closest proper rotation flips the
+                 smallest singular direction, ti.svd's det U = det V = +1 convention)."""
+    write_cube_obj(obj_path, (0.0, 0.0, 0.0), 0.1)
+    sd = fluid_only(counts=(12, 6, 10), start=(0.1, 0.1, 0.1), velocity=(0.4, -0.5, 0.0))
+    body = lambda oid, tr, scale, rho, vel: {
+        "objectId": oid, "geometryFile": obj_path, "translation": list(tr), "rotationAxis": [0, 0, 1], "rotationAngle": 0,
+        "scale": list(scale), "velocity": list(vel), "density": rho, "color": [255, 255, 255], "isDynamic": True}
+    if which == "flat":
+        sd["RigidBodies"] = [body(1, (0.16, 0.24, 0.14), (1, 0.05, 1), 800.0, (0.2, -2.5, 0.1))]
+        moves = {1: ("rot", (0.0, 0.0, 1.0), 25.0)}
+    else:
+        sd["RigidBodies"] = [body(1, (0.12, 0.235, 0.12), (1, 0.6, 0.3), 700.0, (0.2, -2.0, 0.1)),
+                             body(2, (0.25, 0.235, 0.22), (1, 0.6, 0.3), 1500.0, (-0.2, -2.0, 0.0))]
+        moves = {1: ("rot", (1.0, 1.0, 0.0), 179.0), 2: ("mirror", 2, None)}
+
+    def state_fn(arrays):
+        x = np.array(arrays["x"], dtype=np.float32, copy=True)
+        v = np.array(arrays["v"], dtype=np.float32, copy=True)
+        for oid, (kind, a, ang) in moves.items():
+            m = arrays["object_id"] == oid
+            c = x[m].astype(np.float64).mean(axis=0)        # equal masses: the centre of mass
+            q = x[m].astype(np.float64) - c
+            if kind == "rot":
+                k = np.asarray(a, np.float64) / np.linalg.norm(a)
+                th = np.deg2rad(ang)
+                K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+                R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+                q = q @ R.T
+            else:
+                q[:, a] = -q[:, a]
+            x[m] = (c + q).astype(np.float32)
+        return {"x": x, "v": v}
+    return sd, state_fn
+
+
 def as_dfsph(scene_dict, dt=0.002):
     """The same scene under DFSPHSolver (simulationMethod 4, DFSPH.py)."""
     sd = copy.deepcopy(scene_dict)

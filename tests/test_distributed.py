@@ -622,7 +622,8 @@ def test_bench_keeps_the_tiled_line_when_the_c4_object_hangs(tmp_path):
     """ADVICE r04 medium / VERDICT r04 "next" #2c: the supplementary c4_dambreak object gets a wall-clock budget it cannot
     meet (the stand-in for a hang inside it): both ranks' watchdogs end the job, rank 0 prints the FINISHED tiled line with
     c4_dambreak = {error: watchdog, stage: ...}, exit code 0."""
-    p, lines = _bench_two_ranks("torch", "self", extra=("--c4-budget-s", "0.2"))
+    # (the shrunk c4 object finishes in a few hundred ms: it is given 40,000 settling steps and half a second)
+    p, lines = _bench_two_ranks("torch", "self", extra=("--c4-budget-s", "0.5", "--settled-after", "40000"))
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     assert len(lines) == 1, p.stdout.decode()[-2000:]
     d = json.loads(lines[0])

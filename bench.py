@@ -382,6 +382,12 @@ def main():
         it0 = solver.stats()
         dt, tm = run(args.gather_impl, args.brick_shape, 1, args.steps, args.warmup)
         it1 = solver.stats()
+        # A/B on the same state and box: the solver loops with the host round trip per Jacobi iteration put back
+        # (SPH_OPT_DF_RUNAHEAD 0: enqueue, wait, decide) against the default (iteration k + 1 enqueued ahead of k's test)
+        ps.set_option(_lib.OPT_DF_RUNAHEAD, 0)
+        dt_ab0, _ = run(args.gather_impl, args.brick_shape, 1, args.steps, 2)
+        ps.set_option(_lib.OPT_DF_RUNAHEAD, 1)
+        dt_ab1, _ = run(args.gather_impl, args.brick_shape, 1, args.steps, 2)
         k = max(int(tm.steps), 1)
         iv = (it1["total_iterations_v"] - it0["total_iterations_v"]) / (args.warmup + args.steps)
         ip = (it1["total_iterations"] - it0["total_iterations"]) / (args.warmup + args.steps)
@@ -399,7 +405,10 @@ def main():
             "dfsph": {"divergence_iterations_per_step": round(iv, 2), "pressure_iterations_per_step": round(ip, 2),
                       "neighbour_sweeps_per_step": round(sweeps, 2),
                       "ms_per_sweep": round((tm.neighbour_ms + tm.force_ms) / k / sweeps, 4),
-                      "simulated_time_per_wall_second": round(args.steps / dt * DFSPH_DT, 3)},
+                      "simulated_time_per_wall_second": round(args.steps / dt * DFSPH_DT, 3),
+                      "runahead_ab": {"ms_per_step_host_round_trip_per_iteration": round(dt_ab0 / args.steps * 1e3, 4),
+                                      "ms_per_step_run_ahead": round(dt_ab1 / args.steps * 1e3, 4),
+                                      "note": "two further blocks of K steps on the same state: SPH_OPT_DF_RUNAHEAD 0, then 1"}},
             "roofline": None,
         }
         # The step is ~37 neighbour sweeps over unchanged positions; all but the first read the neighbour lists.  Algorithmic
@@ -409,14 +418,33 @@ def main():
         # fraction is a lower bound for the Jacobi sweeps themselves (111-113 us in the kernel trace).
         ms_sweep = line["dfsph"]["ms_per_sweep"]
         ab = 56.0 * N + 4.0 * G
+        # counter traffic of the Jacobi sweep (profiles/pmc_traffic_dfsph.json: tools/gpu_pmc.sh over this command line +
+        # tools/refresh_pmc.py --solver dfsph), quoted only for the kernel sources this library was built from
+        traffic, traffic_note, per_kernel = None, "no PMC file for this revision", None
+        try:
+            from sph_taichi_amd import build as _build
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_dfsph.json")))
+            if pm.get("kernel_fingerprint") != _build._fingerprint():
+                traffic_note = "profiles/pmc_traffic_dfsph.json was measured on other kernel sources (fingerprint differs): not quoted"
+            elif pm.get("workload") != args.workload:
+                traffic_note = "profiles/pmc_traffic_dfsph.json covers another workload: not quoted"
+            else:
+                ks = pm["kernels"]
+                per_kernel = {k_: {"traffic": v["fetch_kb"] * 1024 * 2 + v["write_kb"] * 1024, "dispatches": v.get("dispatches")}
+                              for k_, v in ks.items() if "GM_DF" in k_ and "fetch_kb" in v and "write_kb" in v}
+                it = per_kernel.get("k_gather_brick<GM_DF_DIV_ITER_U>") or per_kernel.get("k_gather_brick<GM_DF_DIV_ITER>")
+                traffic = it["traffic"] if it else None
+                traffic_note = (f"profiles/pmc_traffic_dfsph.json ({pm.get('source')}), same kernel fingerprint; mean over ALL dispatches of "
+                                "the divergence solver's Jacobi sweep, i.e. including the ones enqueued past convergence, which leave at once")
+        except Exception as e:      # noqa: BLE001
+            traffic_note = f"PMC file unusable ({type(e).__name__})"
         if ms_sweep > 0:
             ach = ab / (ms_sweep * 1e-3) / 1e9
             line["roofline"] = {"kernel": "k_gather_brick<GM_DF_*_ITER_U> (list-reading Jacobi sweep; mean over the step's sweeps)",
                                 "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "alg_bytes_per_launch": ab,
-                                "avg_launch_ms": ms_sweep,
-                                "note": "gather sweeps are VALU- / vector-memory-bound, not HBM-bound (DESIGN.md section 3); no PMC pass "
-                                        "exists for the DFSPH kernels, so traffic is null"}
+                                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "alg_bytes_per_launch": ab,
+                                "avg_launch_ms": ms_sweep, "counters": traffic_note, "traffic_by_kernel": per_kernel,
+                                "note": "gather sweeps are VALU- / vector-memory-bound, not HBM-bound (DESIGN.md section 4)"}
         ps.close()
         line["cpu_baseline"] = cpu_baseline(sd, args.cpu_steps) if args.cpu_steps > 0 else None
         print(json.dumps(line), flush=True)

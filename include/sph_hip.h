@@ -139,6 +139,10 @@ enum SphOption {
                                   inside sph_step / sph_dfsph_step, the per-body solid wall passes replayed per particle;
                                   0 = body by body (4 launches each).  Same results bit for bit.  (One launch behind grid-wide
                                   barriers was built too and is slower: commit 98934a4.) */,
+    SPH_OPT_DF_RUNAHEAD = 13,  /* DFSPH solver loops: 1 (default) = the host enqueues Jacobi iteration k + 1 before it waits for
+                                  iteration k's convergence test (made on the device); a body enqueued past convergence
+                                  leaves at once.  0 = enqueue, wait, decide (a host round trip per iteration, as in the
+                                  reference's loop).  Same iteration counts, same results. */
     SPH_OPT_EXACT_MATH = 12    /* A/B of the fast-math choice (never the default): 1 = the brick sweeps of the fused WCSPH step
                                   (density + EOS, force) evaluate r.norm(), r / (|r| h), x / y with IEEE sqrt and divide
                                   as the reference's f32 expressions do, instead of v_rsq_f32 / v_rcp_f32 (~1 ulp).

@@ -131,6 +131,7 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     c->timing_phase = 0;
     c->opt_brick_shape = 0;
     c->opt_rigid_batch = 1;
+    c->opt_df_runahead = 1;
     c->opt_exact_math = 0;
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
@@ -272,6 +273,7 @@ int32_t sph_set_option(SphContext* c, int32_t option, int32_t value) {
         case SPH_OPT_SORT_BY_PID: c->opt_sort_by_pid = value ? 1 : 0; return 0;
         case SPH_OPT_RIGID_BATCH: c->opt_rigid_batch = value ? 1 : 0; return 0;
         case SPH_OPT_EXACT_MATH: c->opt_exact_math = value ? 1 : 0; sph_invalidate_lists(c); return 0;
+        case SPH_OPT_DF_RUNAHEAD: c->opt_df_runahead = value ? 1 : 0; return 0;
         case SPH_OPT_KERNEL_VARIANT:
             if (value < -1 || value > 31 || (value > 0 && (value & 6))) return sph_fail(c, SPH_E_INVALID, "kernel variant must be -1 (default) or a mask of SPH_VAR_*");
             c->opt_variant = value < 0 ? SPH_VAR_DEFAULT : value;
@@ -299,6 +301,7 @@ int32_t sph_get_option(const SphContext* c, int32_t option, int32_t* value) {
         // be one runs the general sweeps with v_rsq / v_rcp whatever was requested, and an A/B must be able to see that
         case SPH_OPT_EXACT_MATH: *value = (c->opt_exact_math && c->uniform_state != 0) ? 1 : 0; return 0;
         case SPH_OPT_KERNEL_VARIANT: *value = c->opt_variant; return 0;
+        case SPH_OPT_DF_RUNAHEAD: *value = c->opt_df_runahead; return 0;
         case SPH_OPT_UNIFORM_FLUID_STATE: *value = c->uniform_state; return 0;
     }
     return SPH_E_INVALID;
@@ -1115,7 +1118,8 @@ static int df_solve_loop(SphContext* c, const DfSolve& s, int* iterations, doubl
     double avg = 0.0;
     while (!rc) {
         const bool more = k + 1 < s.limit;
-        if (more) rc = df_enqueue_body(c, s, k + 1);  // ahead of body k's test; a no-op on the device if that test closes the solve
+        const bool ahead = more && c->opt_df_runahead;
+        if (ahead) rc = df_enqueue_body(c, s, k + 1);  // ahead of body k's test; a no-op on the device if that test closes the solve
         if (rc) break;
         if (hipEventSynchronize(c->ev_df[k & 3]) != hipSuccess) { rc = sph_fail(c, SPH_E_STATE, "DFSPH solver: event wait failed"); break; }
         const volatile SphContext::DfSlot* slot = c->h_df_slot + (k & 3);
@@ -1124,6 +1128,7 @@ static int df_solve_loop(SphContext* c, const DfSolve& s, int* iterations, doubl
         if (slot->converged) break;   // DFSPH.py:262-263 / 348-349
         k += 1;                       // m_iterations += 1
         if (!more) break;             // the while condition: m_iterations reached max(1, m_max_iterations)
+        if (!ahead) rc = df_enqueue_body(c, s, k);
     }
     c->df_epoch_done = c->df_epoch;
     c->df_epoch = 0u;                 // the gate is closed to every kernel outside this loop

@@ -163,6 +163,7 @@ struct SphContext {
     int opt_gather_impl, opt_timing, opt_fused, opt_brick_shape, opt_no_dynamic, opt_ablate, opt_drop_outside;
     int opt_sort_by_pid;
     int opt_rigid_batch;  // SPH_OPT_RIGID_BATCH: 1 (default) = solve_rigid_body() of all bodies in three launches
+    int opt_df_runahead;  // SPH_OPT_DF_RUNAHEAD: 1 = DFSPH solver bodies are enqueued one ahead of the convergence test
     int opt_exact_math;   // SPH_OPT_EXACT_MATH: 1 = IEEE divide / sqrt instances of the brick sweeps (A/B of the fast-math choice)
     int opt_variant;     // SPH_OPT_KERNEL_VARIANT (bit mask of SPH_VAR_*)
     int fuse_advect;     // set around the force launch of sph_step when the advect can ride in its finish

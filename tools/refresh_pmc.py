@@ -25,7 +25,10 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-MODES = {2: "GM_DENSITY", 3: "GM_DENSITY_EOS", 6: "GM_FORCE_FUSED", 14: "GM_FORCE_FUSED_U"}
+MODES = {2: "GM_DENSITY", 3: "GM_DENSITY_EOS", 6: "GM_FORCE_FUSED", 14: "GM_FORCE_FUSED_U",
+         # DFSPH (--solver dfsph passes: profiles/pmc_traffic_dfsph.json)
+         7: "GM_DF_DENSITY", 8: "GM_DF_FACTOR", 9: "GM_DF_DENSITY_CHANGE", 10: "GM_DF_DENSITY_ADV", 11: "GM_DF_DIV_ITER",
+         12: "GM_DF_PRESSURE_ITER", 13: "GM_DF_NONPRESSURE", 15: "GM_DF_DIV_ITER_U", 16: "GM_DF_PRESSURE_ITER_U"}
 
 
 def short_name(kernel: str) -> str:
@@ -86,6 +89,9 @@ def main():
     ap.add_argument("--settled", default="")
     ap.add_argument("--tail", type=int, default=20)
     ap.add_argument("--workload", default="c3p_uniform_1.75M")
+    ap.add_argument("--solver", default="wcsph", help="dfsph: the passes were taken over `bench.py --solver dfsph` (the file then "
+                    "averages ALL dispatches of a kernel unless --tail says otherwise: sweeps enqueued past convergence leave at "
+                    "once and would bias a short tail)")
     a = ap.parse_args()
     from sph_taichi_amd import build
     rest = collect(a.src, a.tail)
@@ -101,6 +107,7 @@ def main():
                     "(GRBM_GUI_ACTIVE / 8 XCDs); lds_active_frac = SQ_LDS_IDX_ACTIVE / 256 CUs / kernel cycles.",
         "kernel_fingerprint": build._fingerprint(),
         "workload": a.workload,
+        "solver": a.solver,
         "source": os.path.basename(os.path.normpath(a.src)) + (" + " + os.path.basename(os.path.normpath(a.settled)) if a.settled else ""),
         "tail": a.tail,
         "kernels": rest,

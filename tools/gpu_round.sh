@@ -11,6 +11,7 @@
 #     nativemp : only the multi-process native-exchange tests (tests/fake_rccl)
 #     timeline : per-workgroup time line of the two brick sweeps (profiling build, tools/brick_timeline.py)
 #     bodies   : the default bench line's with_bodies object alone
+#     pmcdf    : FETCH_SIZE / WRITE_SIZE passes over the DFSPH line -> profiles/pmc_traffic_dfsph.json
 TAG=${1:-round}; shift
 PARTS=${*:-tests pmc kstats bench variants}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -31,6 +32,13 @@ if has pmc; then
   rm -rf gpurun_out/pmc_${TAG}_rest gpurun_out/pmc_${TAG}_settled
   cp $OUT/pmc_traffic.json profiles/pmc_traffic.json
   head -c 1500 $OUT/pmc_brief.json
+fi
+if has pmcdf; then   # HBM traffic of the DFSPH sweeps (FETCH_SIZE / WRITE_SIZE passes over bench.py --solver dfsph) -> profiles/pmc_traffic_dfsph.json
+  PMC_PASSES="fetch write" bash tools/gpu_pmc.sh ${TAG}_dfsph --solver dfsph > $OUT/pmc_dfsph.log 2>&1; tail -n 2 $OUT/pmc_dfsph.log
+  python tools/refresh_pmc.py gpurun_out/pmc_${TAG}_dfsph $OUT/pmc_traffic_dfsph.json --solver dfsph --tail 0 > $OUT/pmc_dfsph_brief.json 2> $OUT/refresh_dfsph.err; echo "refresh dfsph rc=$?"
+  rm -rf gpurun_out/pmc_${TAG}_dfsph
+  cp $OUT/pmc_traffic_dfsph.json profiles/pmc_traffic_dfsph.json
+  head -c 1200 $OUT/pmc_dfsph_brief.json
 fi
 if has kstats; then
   bash tools/gpu_kstats.sh $TAG "--steps 60 --warmup 5 --min-seconds 0 --settled-after 0" "--steps 60 --warmup 5 --settle 2000 --settled-after 0"

@@ -158,6 +158,10 @@ enum SphOption {
 /* (bit 2 was SPH_VAR_RING, the per-lane LDS ring of hit masks with ONE balanced emission loop per lane: built, parity-green,
    slower than GROUPS -- profiles/archive/r03f_variants_partition_x_emission.json, DESIGN.md 4.5 -- and removed after commit 1bbd9b5;
    a mask with that bit set is refused) */
+#define SPH_VAR_MFMA 32     /* density (with GROUPS): the candidate filter on the MATRIX pipe -- v_mfma_f32_16x16x4_f32 tests 16 candidate
+                              rows against 16 target columns; a wave's 64 targets are four tiles of 16 consecutive targets, the
+                              4-bit row pieces reach their target's lane through a v_permlane32/16_swap transpose (round 5:
+                              the A/B the verdict asked for; DESIGN_HISTORY.md).  Same hits, same lists, same sums. */
 #define SPH_VAR_FORCE_BF 8 /* force sweep: branch-free fluid pair term, buffer addressing for list and gather */
 #define SPH_VAR_DEEP 16    /* list-reading sweeps: list entries loaded a whole round (3 pairs) before they are decoded */
 /* (r04: bit 64 was SPH_VAR_PERSIST -- both sweeps as PERSISTENT workgroups, grid = the chip's resident slots, bricks taken by

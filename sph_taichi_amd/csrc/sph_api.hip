@@ -275,7 +275,7 @@ int32_t sph_set_option(SphContext* c, int32_t option, int32_t value) {
         case SPH_OPT_EXACT_MATH: c->opt_exact_math = value ? 1 : 0; sph_invalidate_lists(c); return 0;
         case SPH_OPT_DF_RUNAHEAD: c->opt_df_runahead = value ? 1 : 0; return 0;
         case SPH_OPT_KERNEL_VARIANT:
-            if (value < -1 || value > 31 || (value > 0 && (value & 6))) return sph_fail(c, SPH_E_INVALID, "kernel variant must be -1 (default) or a mask of SPH_VAR_*");
+            if (value < -1 || value > 63 || (value > 0 && (value & 6))) return sph_fail(c, SPH_E_INVALID, "kernel variant must be -1 (default) or a mask of SPH_VAR_*");
             c->opt_variant = value < 0 ? SPH_VAR_DEFAULT : value;
             sph_invalidate_lists(c);
             return 0;

@@ -813,6 +813,7 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool HAS_W = !mode_reads_list<MODE>();
     constexpr bool V_GROUPS = (VAR & SPH_VAR_GROUPS) != 0 && !mode_reads_list<MODE>();
+    constexpr bool V_MFMA = (VAR & SPH_VAR_MFMA) != 0 && V_GROUPS && MODE == GM_DENSITY_EOS;  // the filter on the matrix pipe
     constexpr bool V_BF = (VAR & SPH_VAR_FORCE_BF) != 0 && MODE == GM_FORCE_FUSED_U;
     constexpr bool V_DEEP = (VAR & SPH_VAR_DEEP) != 0 && mode_reads_list<MODE>();
     constexpr bool V_EXACT = (VAR & SPH_VAR_EXACT) != 0 && (MODE == GM_DENSITY_EOS || MODE == GM_FORCE_FUSED_U);  // SPH_OPT_EXACT_MATH
@@ -919,14 +920,14 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
     // the lanes are therefore assigned so that a group only holds cells {0,1} or {2,3}.  The same cache lines are
     // touched by the wave's global accesses either way.
     auto tmap = [&](int tn) -> int {
-        if (mode_reads_list<MODE>() || (tn | 31) >= T) return tn;
+        if (mode_reads_list<MODE>() || V_MFMA || (tn | 31) >= T) return tn;  // (V_MFMA: a tile is 16 CONSECUTIVE targets; no per-lane ds_read_b128 left to place)
         const int l = tn & 31;
         return (tn & ~31) | (int)(((0x73261540u >> ((l >> 2) * 4)) & 7u) << 2) | (l & 3);
     };
     int col_0 = 0, gi_0 = 0, key_0 = 0;
     float4 Ai_0 = make_float4(0.f, 0.f, 0.f, 0.f), Bi_0 = Ai_0, Ei_0 = Ai_0;
-    if (tid < T) {
-        const int tq = tmap(tid);
+    if (V_MFMA || tid < T) {   // (V_MFMA: every lane of a wave that holds a target takes part in the tiles: lanes past T mirror target T - 1)
+        const int tq = tmap(V_MFMA ? min(tid, T - 1) : tid);
 #pragma unroll
         for (int step = 16; step > 0; step >>= 1)
             if (sTOff[col_0 + step] <= tq) col_0 += step;
@@ -989,11 +990,12 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
     SPH_TS(2);
 
     // ---- step C: targets ----
-    for (int tn = tid; tn < T; tn += TPB) {
+    for (int tn = tid; V_MFMA ? (tn & ~63) < T : tn < T; tn += TPB) {
+        const bool valid = !V_MFMA || tn < T;   // V_MFMA: whole waves run the loop (wave-uniform trip count), lanes past T idle
         int col = col_0, gi = gi_0, key_i = key_0;
         float4 Ai = Ai_0, Bi = Bi_0, Ei = Ei_0;
         if (tn != tid) {  // later rounds (bricks with more than 256 targets)
-            const int tq = tmap(tn);
+            const int tq = tmap(V_MFMA ? min(tn, T - 1) : tn);
             col = 0;
 #pragma unroll
             for (int step = 16; step > 0; step >>= 1)
@@ -1015,9 +1017,97 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
         }
         Target t;
         target_init<MODE, V_EXACT>(d, t, Ai, Bi, Ei);
-        const bool g = target_gathers<MODE>(t.flags);
+        const bool g = valid && target_gathers<MODE>(t.flags);
         bool walk = g && overflow;
         int cnt = 0;
+        // ---- V_MFMA: the hit masks of the nine runs' first 32 candidates for all 64 targets of the wave, on the matrix pipe.
+        // One v_mfma_f32_16x16x4_f32 = 16 candidate rows (A: (|x'|^2, -2z', -2y', -2x') of a staged record, one component per lane
+        // quarter) x 16 target columns (B: (1, z', y', x') of 16 consecutive targets); D[row][col] = r^2 - |x_i'|^2, compared with
+        // the target's threshold.  Lane l holds rows 4 (l >> 4) .. + 3 of column l & 15: candidate -> row is permuted so that
+        // a lane quarter collects a CONTIGUOUS block of the rows, and after the four tiles of a run a 4 x 4 transpose of the four
+        // mask registers (v_permlane32_swap + v_permlane16_swap) hands every lane the four blocks of ITS OWN target.
+        // Rows = the union of the z windows of the tile's targets in one (x, y) column (a tile that straddles columns runs
+        // once per column).  Everything below is wave-uniform control flow: EXEC is all ones at every MFMA.
+        unsigned mfma_mk[9] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        unsigned mfma_big = 0u;   // bit r: run r has a tile with more than 64 rows -- that run takes the VALU filter
+        if (V_MFMA && !overflow) {
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            typedef unsigned v2u __attribute__((ext_vector_type(2)));
+            const int ixm = sx0 + col / ncy, iym = sy0 + col % ncy;
+            const int czm = key_i - sph_flatten(d, ixm, iym, 0);
+            const int cellidx = ((ixm - cx0) * CFG::BY + (iym - cy0)) * CFG::BZ + (czm - cz0);   // row of the run table
+            const float mx = t.x - Ox, my = t.y - Oy, mz = t.z - Oz;
+            const float mthr = g ? d.h * d.h * 1.0002f - (mx * mx + my * my + mz * mz) : -INFINITY;   // idle lanes: no hit
+            const int q4 = lane >> 4, j16 = lane & 15;
+            float Bop[4], bthr[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int src = 16 * gq + j16;
+                const float bx = __shfl(mx, src, 64), by = __shfl(my, src, 64), bz = __shfl(mz, src, 64);
+                bthr[gq] = __shfl(mthr, src, 64);
+                Bop[gq] = q4 == 0 ? 1.0f : q4 == 1 ? bz : q4 == 2 ? by : bx;   // k = 0 pairs with |x_j'|^2, k = 1..3 with -2 z', -2 y', -2 x'
+            }
+            const unsigned* const sRunAll = reinterpret_cast<const unsigned*>(smem + CFG::off_run(HAS_W));
+            // byte offset of this lane's A component inside a record, and of its row inside a block layout with stride 4C records
+            const unsigned a_comp = (unsigned)(CFG::OFF_Q + (3 - q4) * 4 + (j16 & 3) * 16);
+            const unsigned a_blk = (unsigned)(j16 >> 2);
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {   // (unrolled: the masks live in registers, a run index in a register would send them to scratch)
+                unsigned m4[4] = {0u, 0u, 0u, 0u};
+                int rloL = 0, s1L = 0;   // of this lane's OWN target: first row and 4 C of its (tile, column)
+                bool big = false;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    unsigned rem = 0xffffu;
+                    while (rem) {   // the distinct (x, y) columns of tile gq (targets are ordered by column, then z cell)
+                        const int first = __builtin_ctz(rem);
+                        const int colX = __builtin_amdgcn_readlane(col, 16 * gq + first);
+                        const unsigned long long bal = __ballot(col == colX);
+                        const unsigned sel = (unsigned)(bal >> (16 * gq)) & rem;
+                        rem &= ~sel;
+                        const int last = 31 - __builtin_clz(sel);
+                        const int cmin = __builtin_amdgcn_readlane(cellidx, 16 * gq + first);
+                        const int cmax = __builtin_amdgcn_readlane(cellidx, 16 * gq + last);
+                        const unsigned w1 = __builtin_amdgcn_readfirstlane(sRunAll[cmin * 9 + r]);
+                        const unsigned w2 = __builtin_amdgcn_readfirstlane(sRunAll[cmax * 9 + r]);
+                        const int rlo = (int)(w1 & 2047u), rhi = (int)(w2 & 2047u) + (int)(w2 >> 16);
+                        const int nrows = rhi - rlo;
+                        if (nrows > 64) big = true;
+                        const int C = nrows > 64 ? 0 : (nrows + 15) >> 4;
+                        unsigned mx_ = 0u;
+                        const unsigned abase = a_comp + (unsigned)rlo * 16u + a_blk * (unsigned)(C * 64);
+                        for (int c = C - 1; c >= 0; --c) {
+                            const float a = *reinterpret_cast<const float*>(smem + abase + (unsigned)c * 64u);
+                            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                            const f32x4 dd = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bop[gq], z4, 0, 0, 0);
+                            mx_ = __builtin_amdgcn_alignbit(mx_, __float_as_uint(dd[3] - bthr[gq]), 31);
+                            mx_ = __builtin_amdgcn_alignbit(mx_, __float_as_uint(dd[2] - bthr[gq]), 31);
+                            mx_ = __builtin_amdgcn_alignbit(mx_, __float_as_uint(dd[1] - bthr[gq]), 31);
+                            mx_ = __builtin_amdgcn_alignbit(mx_, __float_as_uint(dd[0] - bthr[gq]), 31);
+                        }
+                        // lanes whose COLUMN-j target (tile gq) sits in column X keep this mask; the lanes of tile gq whose OWN
+                        // target sits in column X remember the rows' origin and the block size
+                        const bool mine_piece = ((sel >> j16) & 1u) != 0u;
+                        m4[gq] = mine_piece ? mx_ : m4[gq];
+                        const bool mine_own = q4 == gq && mine_piece;
+                        rloL = mine_own ? rlo : rloL;
+                        s1L = mine_own ? 4 * C : s1L;
+                    }
+                }
+                // 4 x 4 transpose: piece q of target (16 G + J) moves from lane 16 q + J of register G to lane 16 G + J of register q
+                v2u s02 = __builtin_amdgcn_permlane32_swap(m4[0], m4[2], false, false);
+                v2u s13 = __builtin_amdgcn_permlane32_swap(m4[1], m4[3], false, false);
+                v2u p01 = __builtin_amdgcn_permlane16_swap(s02.x, s13.x, false, false);
+                v2u p23 = __builtin_amdgcn_permlane16_swap(s02.y, s13.y, false, false);
+                const unsigned a01 = p01.x | (p01.y << s1L), a23 = p23.x | (p23.y << s1L);
+                const unsigned long long m64 = (unsigned long long)a01 | ((unsigned long long)a23 << (2 * s1L));
+                const unsigned w = sRunAll[cellidx * 9 + r];
+                const int lo = (int)(w & 2047u), len = (int)(w >> 16);
+                const unsigned win = (unsigned)(m64 >> (lo - rloL));
+                mfma_mk[r] = len > 0 ? (win & (0xffffffffu >> (32 - min(len, 32)))) : 0u;
+                if (__any(big)) mfma_big |= 1u << r;
+            }
+        }
         if (g && !overflow && !mode_reads_list<MODE>() && !SPH_ABL(d, 4)) {
             const int ix = sx0 + col / ncy, iy = sy0 + col % ncy;
             const int cz = key_i - sph_flatten(d, ix, iy, 0);  // key = flatten(ix, iy, cz)
@@ -1117,7 +1207,8 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                 for (int r = 0; r < 9; ++r) {
                     const unsigned w = runs[r];
                     const int len = (int)(w >> 16);
-                    mk[r] = len > 0 ? filter_chunk((int)(w & 2047u), min(32, len)) : 0u;
+                    if (V_MFMA && !((mfma_big >> r) & 1u)) mk[r] = mfma_mk[r];
+                    else mk[r] = len > 0 ? filter_chunk((int)(w & 2047u), min(32, len)) : 0u;
                     tk[r] = w & 0xffffu;
                     longrun |= len > 32;
                 }
@@ -1278,7 +1369,7 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
             gather_walk_global<mode_walk<MODE>()>(d, t, gi);
         }
         SPH_TS(3);
-        target_finish<MODE, V_EXACT>(d, t, gi, g, Ei);
+        if (valid) target_finish<MODE, V_EXACT>(d, t, gi, g, Ei);
     }
     SPH_TS(4);
     }
@@ -1480,6 +1571,7 @@ static int launch_brick(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, in
     const int var = c->opt_variant;
     if constexpr (MODE == GM_DENSITY_EOS) {
         if (c->opt_exact_math) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS | SPH_VAR_EXACT>(c, lo, hi, lo2, hi2);
+        if ((var & SPH_VAR_GROUPS) && (var & SPH_VAR_MFMA)) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS | SPH_VAR_MFMA>(c, lo, hi, lo2, hi2);
         if (var & SPH_VAR_GROUPS) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS>(c, lo, hi, lo2, hi2);
     }
     if constexpr (MODE == GM_FORCE_FUSED_U) {

@@ -8,7 +8,7 @@ import scenes
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [0, 1, 8, 16, 24, 25]      # baseline; GROUPS; the force bits; default = GROUPS | BF | DEEP
+VARIANTS = [0, 1, 8, 16, 24, 25, 57]  # baseline; GROUPS; the force bits; default = GROUPS | BF | DEEP; 57 = default | MFMA (the filter on the matrix pipe)
 
 
 def _system(sd, arrays, variant):
@@ -41,7 +41,7 @@ def test_variant_follows_the_oracle(variant):
     ps.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 24, 25])
+@pytest.mark.parametrize("variant", [0, 1, 24, 25, 57])
 def test_variant_on_crowded_cells(variant):
     """12^3 particles in a (1.5 h)^3 box: > 95 neighbours each, so every list overflows (the force sweep must
     fall back to the exact walk; the range-checked list stores must drop rows >= LISTCAP and nothing else)."""
@@ -81,7 +81,7 @@ def test_variants_agree_with_each_other_on_a_ragged_lattice():
             assert err <= tol, f"variant {variant} vs 0: {n}: {err:.3e}"
 
 
-@pytest.mark.parametrize("variant", [0, 24, 25])
+@pytest.mark.parametrize("variant", [0, 24, 25, 57])
 def test_long_lists_between_64_and_95_entries(variant):
     """A slab compressed to ~2.5 x rest density (spacing 0.74 d): 65..95 list entries per interior particle -- beyond
     the 63 of round 1, inside LISTCAP = 95 -- so the list rows >= 64 are written by the density sweep and read back

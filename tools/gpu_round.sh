@@ -12,6 +12,8 @@
 #     timeline : per-workgroup time line of the two brick sweeps (profiling build, tools/brick_timeline.py)
 #     bodies   : the default bench line's with_bodies object alone
 #     pmcdf    : FETCH_SIZE / WRITE_SIZE passes over the DFSPH line -> profiles/pmc_traffic_dfsph.json
+#     ranks2   : bench.py --gpus 2 without a launcher on the one GPU (torch transport / NativeTransport through tests/fake_rccl)
+#     dfgaps   : GPU idle time between the kernels of the DFSPH line
 TAG=${1:-round}; shift
 PARTS=${*:-tests pmc kstats bench variants}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -39,6 +41,18 @@ if has pmcdf; then   # HBM traffic of the DFSPH sweeps (FETCH_SIZE / WRITE_SIZE 
   rm -rf gpurun_out/pmc_${TAG}_dfsph
   cp $OUT/pmc_traffic_dfsph.json profiles/pmc_traffic_dfsph.json
   head -c 1200 $OUT/pmc_dfsph_brief.json
+fi
+if has ranks2; then   # bench.py --gpus 2 WITHOUT a launcher, both ranks on this one GPU (gloo bootstrap): torch transport and NativeTransport through the librccl stand-in
+  FAKE=$(python -c "import importlib.util,os;s=importlib.util.spec_from_file_location('b','tests/fake_rccl/build.py');m=importlib.util.module_from_spec(s);s.loader.exec_module(m);print(m.build())")
+  SPH_DIST_BACKEND=gloo SPH_C4_SCALE=0.4 SPH_TRANSPORT=torch timeout 600 python bench.py --gpus 2 --steps 20 --warmup 5 --settled-after 200 --preheat-ms 0 > $OUT/bench_2ranks_one_gpu_torch.json 2> $OUT/bench_2ranks_torch.err; echo "2 ranks torch rc=$?"
+  SPH_DIST_BACKEND=gloo SPH_C4_SCALE=0.4 SPH_TRANSPORT=native SPH_RCCL_LIB=$FAKE FAKE_RCCL_SLOT_BYTES=1048576 FAKE_RCCL_SLOTS=3 FAKE_RCCL_TIMEOUT_S=25 timeout 600 python bench.py --gpus 2 --steps 20 --warmup 5 --settled-after 200 --preheat-ms 0 > $OUT/bench_2ranks_one_gpu_native.json 2> $OUT/bench_2ranks_native.err; echo "2 ranks native rc=$?"
+  for f in torch native; do python -c "import json;d=json.load(open('$OUT/bench_2ranks_one_gpu_$f.json'));print('$f', d['value'], d['config']['transport'], d['config']['comm'], d['config']['particles_owned_per_rank'], 'c4', d['c4_dambreak'].get('from_rest',{}).get('value'), d['c4_dambreak'].get('conserved'))"; done
+fi
+if has dfgaps; then   # GPU idle time between the kernels of the DFSPH line (tools/ktrace_gaps.py)
+  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/profd -o prof --output-format csv -- python $R/bench.py --cpu-steps 0 --steps 30 --warmup 3 --solver dfsph > $OUT/rocprof_dfsph.log 2>&1 )
+  f=$(find $OUT/profd -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats_dfsph.csv
+  t=$(find $OUT/profd -name "*kernel_trace.csv" | head -1); [ -n "$t" ] && python tools/ktrace_gaps.py "$t" > $OUT/dfsph_gaps.txt 2>&1 && head -n 6 $OUT/dfsph_gaps.txt
+  rm -rf $OUT/profd
 fi
 if has kstats; then
   bash tools/gpu_kstats.sh $TAG "--steps 60 --warmup 5 --min-seconds 0 --settled-after 0" "--steps 60 --warmup 5 --settle 2000 --settled-after 0"

@@ -831,7 +831,11 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
     int* sTOff = reinterpret_cast<int*>(smem + CFG::off_toff(HAS_W));  // target-number start of the column (+ total at [64])
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (mode_is_df_gated<MODE>() && d.gate && *d.gate == d.gate_epoch) return;  // a solver iteration enqueued past convergence
+    // A DFSPH solver iteration enqueued past convergence leaves without touching anything (DevView::gate).  The gate word is
+    // REQUESTED here and looked at behind step A's barrier: as the first thing a workgroup waits for, its scalar load cost
+    // every sweep of a solve ~2 % (r05: 2.97 vs 2.91 ms per DFSPH step); under the column-table loads it costs nothing.
+    unsigned gate_word = 0u;
+    if (mode_is_df_gated<MODE>() && d.gate) gate_word = *d.gate;
 
     // One workgroup per LISTED brick (the hardware scheduler balances them).  Hardware block b runs on XCD b%8:
     // XCD x takes the x-th eighth of the list, so neighbouring bricks share that XCD's L2 and -- because the list
@@ -903,6 +907,7 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
     }
     __syncthreads();
     SPH_TS(1);
+    if (mode_is_df_gated<MODE>() && d.gate && gate_word == d.gate_epoch) return;  // (no barrier lies ahead of a workgroup that leaves here)
     const int T = sTOff[64];
     const int total = sColS[64];
     if (T == 0) return;

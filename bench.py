@@ -387,16 +387,16 @@ def main():
         dt, tm = run(args.gather_impl, args.brick_shape, 1, args.steps, args.warmup)
         it1 = solver.stats()
         # A/B on the same box over the SAME steps (the run is deterministic: the initial state is restored by persistent id):
-        # the solver loops with the host round trip per Jacobi iteration put back (SPH_OPT_DF_RUNAHEAD 0: enqueue, wait,
-        # decide) against the default above (iteration k + 1 enqueued ahead of iteration k's device-side test)
+        # the solver loops running AHEAD of their convergence tests (SPH_OPT_DF_RUNAHEAD 1: iteration k + 1 enqueued before
+        # the host waits for iteration k's device-side test) against the default above (enqueue, wait, decide)
         pid = ps.pid.to_numpy()
         ps.x.from_numpy(x_by_pid[pid]); ps.v.from_numpy(v_by_pid[pid])
         solver.initialize()
-        ps.set_option(_lib.OPT_DF_RUNAHEAD, 0)
-        dt_ab0, _ = run(args.gather_impl, args.brick_shape, 1, args.steps, args.warmup)
-        it2 = solver.stats()
         ps.set_option(_lib.OPT_DF_RUNAHEAD, 1)
-        dt_ab1 = dt
+        dt_ab1, _ = run(args.gather_impl, args.brick_shape, 1, args.steps, args.warmup)
+        it2 = solver.stats()
+        ps.set_option(_lib.OPT_DF_RUNAHEAD, 0)
+        dt_ab0 = dt
         same_counts = (it2["total_iterations_v"] - it1["total_iterations_v"] == it1["total_iterations_v"] - it0["total_iterations_v"] and
                        it2["total_iterations"] - it1["total_iterations"] == it1["total_iterations"] - it0["total_iterations"])
         k = max(int(tm.steps), 1)
@@ -420,8 +420,8 @@ def main():
                       "runahead_ab": {"ms_per_step_host_round_trip_per_iteration": round(dt_ab0 / args.steps * 1e3, 4),
                                       "ms_per_step_run_ahead": round(dt_ab1 / args.steps * 1e3, 4),
                                       "same_iteration_counts": bool(same_counts),
-                                      "note": "the same W + K steps from the restored initial state with SPH_OPT_DF_RUNAHEAD 0; "
-                                              "run_ahead = the line's own block"}},
+                                      "note": "the same W + K steps from the restored initial state with SPH_OPT_DF_RUNAHEAD 1; "
+                                              "host_round_trip_per_iteration = the line's own block (the default)"}},
             "roofline": None,
         }
         # The step is ~37 neighbour sweeps over unchanged positions; all but the first read the neighbour lists.  Algorithmic

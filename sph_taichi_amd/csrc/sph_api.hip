@@ -53,7 +53,7 @@ DevView sph_view(const SphContext* c) {
     d.m_u = c->m_uniform; d.write_sg = 0; d.write_k = 0;
     d.whx = p.wall_hi[0]; d.why = p.wall_hi[1]; d.whz = p.wall_hi[2];
     d.fuse_advect = c->fuse_advect;
-    d.gate = c->df_epoch ? c->df_gate : nullptr;
+    d.gate = (c->df_epoch && c->opt_df_runahead) ? c->df_gate : nullptr;   // (without run-ahead no body is ever enqueued past convergence)
     d.gate_epoch = c->df_epoch;
     d.fx_scale = ldexp(1.0, c->rigid_fx_exp);
     d.store_acc = !(c->fuse_advect && c->skip_acc);
@@ -131,7 +131,7 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     c->timing_phase = 0;
     c->opt_brick_shape = 0;
     c->opt_rigid_batch = 1;
-    c->opt_df_runahead = 1;
+    c->opt_df_runahead = 0;   // measured (r05): running ahead costs 2 % more than the bubbles it removes
     c->opt_exact_math = 0;
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {

@@ -104,14 +104,15 @@ def test_watchdog_keeps_a_finished_line_when_the_supplementary_object_hangs(tmp_
 
 def test_a_rank_stopped_by_the_launcher_still_names_its_stage(tmp_path):
     """torch.distributed.run ends the surviving ranks with SIGTERM when one rank fails; rank 0, stuck inside a C call, must
-    still leave a line: the signal is taken by a sigwait thread, not by a Python handler."""
+    still leave a line: the signal is taken through a wake-up socket by a thread of the watchdog, not by a Python handler."""
     body = _script(tmp_path, """
         import ctypes
         from sph_taichi_amd.benchutil import Watchdog
         wd = Watchdog(0, 2, total_s=120.0, metric="m", take_sigterm=True)
         wd.stage("tiled: initialize (first exchange + sort)")
         print("ready", file=sys.stderr, flush=True)
-        ctypes.CDLL(None).sleep(100)       # the main thread is inside C and holds no bytecode boundary for a handler
+        while True:                        # the main thread is inside C (a signal that lands on it only makes the call
+            ctypes.CDLL(None).sleep(100)   # return early: it goes straight back in, as a collective would be retried)
     """)
     p = subprocess.Popen([sys.executable, body], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert b"ready" in p.stderr.readline()

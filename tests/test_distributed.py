@@ -183,6 +183,29 @@ def test_local_slabs_restart_from_a_state(which):
     assert scenes.rel_l2(x, ref) <= 2e-6
 
 
+@pytest.mark.gpu
+def test_interior_accelerations_are_refused_while_they_are_not_materialised():
+    """in slab mode the interior force sweep integrates its targets in its finish and does not write their
+    accelerations out; a download used to return stale values silently.  Now it fails with a message, and a stand-alone
+    force computation makes the field readable again."""
+    from sph_taichi_amd import _lib
+    from sph_taichi_amd.distributed import SlabSolver, run_local_slabs
+    sd = _slab_scenes()[0]
+    solvers = [SlabSolver(sd, r, 2, device=0) for r in range(2)]
+    run_local_slabs(solvers, 0, initialize=True)
+    run_local_slabs(solvers, 3)
+    ps = solvers[0].ps
+    if ps.get_option(_lib.OPT_UNIFORM_FLUID_STATE) == 1:      # the fused interior advect ran: the field is partial
+        with pytest.raises(_lib.SphError, match="acceleration"):
+            ps.acceleration.to_numpy()
+        ps._call("sph_compute_non_pressure_forces")
+        ps._call("sph_compute_pressure_forces")
+    a = ps.acceleration.to_numpy()
+    assert np.isfinite(a).all()
+    for s in solvers:
+        s.close()
+
+
 def test_plan_recut_moves_one_layer_towards_balance():
     from sph_taichi_amd.distributed import plan_recut
     from sph_taichi_amd.scene import slab_cuts

@@ -200,8 +200,8 @@ def test_interior_accelerations_are_refused_while_they_are_not_materialised():
             ps.acceleration.to_numpy()
         ps._call("sph_compute_non_pressure_forces")
         ps._call("sph_compute_pressure_forces")
-    a = ps.acceleration.to_numpy()
-    assert np.isfinite(a).all()
+    a = solvers[0].owned(("pid", "acceleration"))["acceleration"]     # (the outer ghost layer has no density: only owned rows mean anything)
+    assert a.shape[0] == solvers[0].owned_range[1] and np.isfinite(a).all() and np.abs(a).max() > 0.0
     for s in solvers:
         s.close()
 

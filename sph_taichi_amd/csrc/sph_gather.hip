@@ -1056,47 +1056,109 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
             // byte offset of this lane's A component inside a record, and of its row inside a block layout with stride 4C records
             const unsigned a_comp = (unsigned)(CFG::OFF_Q + (3 - q4) * 4 + (j16 & 3) * 16);
             const unsigned a_blk = (unsigned)(j16 >> 2);
+            // -- the (x, y) columns of the four tiles, ONCE per round: a tile's targets are ordered by column, then z cell, so it
+            // holds at most... usually one or two columns (slot A = the first lane's, slot B = the next one); a tile with a
+            // third column sends the whole wave to the VALU filter (columns of < 8 targets: the fluid's surface and edges)
+            unsigned selB[4];          // which of the tile's 16 targets sit in slot B's column (0: none)
+            int cA0[4], cA1[4], cB0[4], cB1[4];   // run-table rows of the first / last target of each slot
+            bool slow = false;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int colA = __builtin_amdgcn_readlane(col, 16 * gq);
+                const unsigned sA = (unsigned)(__ballot(col == colA) >> (16 * gq)) & 0xffffu;
+                const unsigned remB = 0xffffu & ~sA;
+                cA0[gq] = __builtin_amdgcn_readlane(cellidx, 16 * gq);
+                cA1[gq] = __builtin_amdgcn_readlane(cellidx, 16 * gq + 31 - __builtin_clz(sA));
+                selB[gq] = 0u; cB0[gq] = cA0[gq]; cB1[gq] = cA0[gq];
+                if (remB) {
+                    const int fb = __builtin_ctz(remB);
+                    const int colB = __builtin_amdgcn_readlane(col, 16 * gq + fb);
+                    const unsigned sB = (unsigned)(__ballot(col == colB) >> (16 * gq)) & remB;
+                    if (remB & ~sB) slow = true;
+                    selB[gq] = sB;
+                    cB0[gq] = __builtin_amdgcn_readlane(cellidx, 16 * gq + fb);
+                    cB1[gq] = __builtin_amdgcn_readlane(cellidx, 16 * gq + 31 - __builtin_clz(sB));
+                }
+            }
+            // -- the row ranges of all (tile, slot, run) at once: lane 9 * tile + run reads the run-table words of the slot's first
+            // and last target cell -- two LDS round trips for the whole round instead of two per pass
+            const int tl = lane / 9 < 4 ? lane / 9 : 3, rl = lane % 9;
+            int va0 = cA0[0], va1 = cA1[0], vb0 = cB0[0], vb1 = cB1[0];
+#pragma unroll
+            for (int gq = 1; gq < 4; ++gq) {
+                va0 = tl == gq ? cA0[gq] : va0; va1 = tl == gq ? cA1[gq] : va1;
+                vb0 = tl == gq ? cB0[gq] : vb0; vb1 = tl == gq ? cB1[gq] : vb1;
+            }
+            const unsigned wa0 = sRunAll[va0 * 9 + rl], wa1 = sRunAll[va1 * 9 + rl];
+            const unsigned wb0 = sRunAll[vb0 * 9 + rl], wb1 = sRunAll[vb1 * 9 + rl];
+            const int rloA = (int)(wa0 & 2047u), nA = (int)(wa1 & 2047u) + (int)(wa1 >> 16) - rloA;
+            const int rloB = (int)(wb0 & 2047u), nB = (int)(wb1 & 2047u) + (int)(wb1 >> 16) - rloB;
+            const unsigned tabA = (unsigned)rloA | ((unsigned)(nA > 0 ? nA : 0) << 11);   // (rows | count << 11), count up to the tile
+            const unsigned tabB = (unsigned)rloB | ((unsigned)(nB > 0 ? nB : 0) << 11);
+            {   // runs with a pass of more than 64 rows (crowded cells) take the VALU filter; so does everything in a slow wave
+                const bool bigl = lane < 36 && (nA > 64 || (nB > 64 && selB[tl] != 0u));
+                unsigned bb = bigl ? (1u << rl) : 0u;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) bb |= __shfl_xor(bb, off, 64);
+                mfma_big = slow ? 0x1ffu : bb;
+            }
+            // one pass = one (tile, slot, run): up to four chunks of 16 rows; loads first, then the MFMAs back to back on
+            // independent accumulators, then the sign bits
+            auto pass = [&](unsigned pk, int gq) -> unsigned {
+                const int rlo = (int)(pk & 2047u), nrows = (int)(pk >> 11);
+                const int C = nrows > 64 ? 0 : (nrows + 15) >> 4;
+                unsigned mx_ = 0u;
+                if (C > 0) {
+                    const unsigned abase = a_comp + (unsigned)rlo * 16u + a_blk * (unsigned)(C * 64);
+                    // (chunks past C re-read chunk 0: a harmless load that keeps the four requests unconditional)
+                    const float a0 = *reinterpret_cast<const float*>(smem + abase);
+                    const float a1 = *reinterpret_cast<const float*>(smem + abase + (C > 1 ? 64u : 0u));
+                    const float a2 = *reinterpret_cast<const float*>(smem + abase + (C > 2 ? 128u : 0u));
+                    const float a3 = *reinterpret_cast<const float*>(smem + abase + (C > 3 ? 192u : 0u));
+                    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                    const float bt = bthr[gq];
+#define SPH_SIGN4(D_) mx_ = __builtin_amdgcn_alignbit(mx_, __float_as_uint((D_)[3] - bt), 31); \
+                      mx_ = __builtin_amdgcn_alignbit(mx_, __float_as_uint((D_)[2] - bt), 31); \
+                      mx_ = __builtin_amdgcn_alignbit(mx_, __float_as_uint((D_)[1] - bt), 31); \
+                      mx_ = __builtin_amdgcn_alignbit(mx_, __float_as_uint((D_)[0] - bt), 31);
+                    if (C > 2) {
+                        const f32x4 d3 = C > 3 ? __builtin_amdgcn_mfma_f32_16x16x4f32(a3, Bop[gq], z4, 0, 0, 0) : z4;
+                        const f32x4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, Bop[gq], z4, 0, 0, 0);
+                        const f32x4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, Bop[gq], z4, 0, 0, 0);
+                        const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, Bop[gq], z4, 0, 0, 0);
+                        if (C > 3) { SPH_SIGN4(d3) }
+                        SPH_SIGN4(d2) SPH_SIGN4(d1) SPH_SIGN4(d0)
+                    } else {
+                        const f32x4 d1 = C > 1 ? __builtin_amdgcn_mfma_f32_16x16x4f32(a1, Bop[gq], z4, 0, 0, 0) : z4;
+                        const f32x4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, Bop[gq], z4, 0, 0, 0);
+                        if (C > 1) { SPH_SIGN4(d1) }
+                        SPH_SIGN4(d0)
+                    }
+#undef SPH_SIGN4
+                }
+                return mx_;
+            };
 #pragma unroll
             for (int r = 0; r < 9; ++r) {   // (unrolled: the masks live in registers, a run index in a register would send them to scratch)
-                unsigned m4[4] = {0u, 0u, 0u, 0u};
+                unsigned m4[4];
                 int rloL = 0, s1L = 0;   // of this lane's OWN target: first row and 4 C of its (tile, column)
-                bool big = false;
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {
-                    unsigned rem = 0xffffu;
-                    while (rem) {   // the distinct (x, y) columns of tile gq (targets are ordered by column, then z cell)
-                        const int first = __builtin_ctz(rem);
-                        const int colX = __builtin_amdgcn_readlane(col, 16 * gq + first);
-                        const unsigned long long bal = __ballot(col == colX);
-                        const unsigned sel = (unsigned)(bal >> (16 * gq)) & rem;
-                        rem &= ~sel;
-                        const int last = 31 - __builtin_clz(sel);
-                        const int cmin = __builtin_amdgcn_readlane(cellidx, 16 * gq + first);
-                        const int cmax = __builtin_amdgcn_readlane(cellidx, 16 * gq + last);
-                        const unsigned w1 = __builtin_amdgcn_readfirstlane(sRunAll[cmin * 9 + r]);
-                        const unsigned w2 = __builtin_amdgcn_readfirstlane(sRunAll[cmax * 9 + r]);
-                        const int rlo = (int)(w1 & 2047u), rhi = (int)(w2 & 2047u) + (int)(w2 >> 16);
-                        const int nrows = rhi - rlo;
-                        if (nrows > 64) big = true;
-                        const int C = nrows > 64 ? 0 : (nrows + 15) >> 4;
-                        unsigned mx_ = 0u;
-                        const unsigned abase = a_comp + (unsigned)rlo * 16u + a_blk * (unsigned)(C * 64);
-                        for (int c = C - 1; c >= 0; --c) {
-                            const float a = *reinterpret_cast<const float*>(smem + abase + (unsigned)c * 64u);
-                            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                            const f32x4 dd = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bop[gq], z4, 0, 0, 0);
-                            mx_ = __builtin_amdgcn_alignbit(mx_, __float_as_uint(dd[3] - bthr[gq]), 31);
-                            mx_ = __builtin_amdgcn_alignbit(mx_, __float_as_uint(dd[2] - bthr[gq]), 31);
-                            mx_ = __builtin_amdgcn_alignbit(mx_, __float_as_uint(dd[1] - bthr[gq]), 31);
-                            mx_ = __builtin_amdgcn_alignbit(mx_, __float_as_uint(dd[0] - bthr[gq]), 31);
-                        }
-                        // lanes whose COLUMN-j target (tile gq) sits in column X keep this mask; the lanes of tile gq whose OWN
-                        // target sits in column X remember the rows' origin and the block size
-                        const bool mine_piece = ((sel >> j16) & 1u) != 0u;
-                        m4[gq] = mine_piece ? mx_ : m4[gq];
-                        const bool mine_own = q4 == gq && mine_piece;
-                        rloL = mine_own ? rlo : rloL;
-                        s1L = mine_own ? 4 * C : s1L;
+                    const unsigned pkA = __builtin_amdgcn_readlane(tabA, 9 * gq + r);
+                    m4[gq] = pass(pkA, gq);
+                    const bool own = q4 == gq;
+                    const int nrA = (int)(pkA >> 11);
+                    rloL = own ? (int)(pkA & 2047u) : rloL;
+                    s1L = own ? ((nrA + 15) >> 4) * 4 : s1L;
+                    if (selB[gq]) {   // the tile straddles two columns: a second pass over the other column's rows
+                        const unsigned pkB = __builtin_amdgcn_readlane(tabB, 9 * gq + r);
+                        const unsigned mB = pass(pkB, gq);
+                        const bool pieceB = ((selB[gq] >> j16) & 1u) != 0u;      // the piece's target (column j of the tile) sits in slot B's column
+                        m4[gq] = pieceB ? mB : m4[gq];
+                        const bool ownB = own && pieceB;
+                        const int nrB = (int)(pkB >> 11);
+                        rloL = ownB ? (int)(pkB & 2047u) : rloL;
+                        s1L = ownB ? ((nrB + 15) >> 4) * 4 : s1L;
                     }
                 }
                 // 4 x 4 transpose: piece q of target (16 G + J) moves from lane 16 q + J of register G to lane 16 G + J of register q
@@ -1108,9 +1170,8 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                 const unsigned long long m64 = (unsigned long long)a01 | ((unsigned long long)a23 << (2 * s1L));
                 const unsigned w = sRunAll[cellidx * 9 + r];
                 const int lo = (int)(w & 2047u), len = (int)(w >> 16);
-                const unsigned win = (unsigned)(m64 >> (lo - rloL));
+                const unsigned win = (unsigned)(m64 >> ((lo - rloL) & 63));
                 mfma_mk[r] = len > 0 ? (win & (0xffffffffu >> (32 - min(len, 32)))) : 0u;
-                if (__any(big)) mfma_big |= 1u << r;
             }
         }
         if (g && !overflow && !mode_reads_list<MODE>() && !SPH_ABL(d, 4)) {

@@ -1138,8 +1138,10 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                 }
                 return mx_;
             };
-#pragma unroll
-            for (int r = 0; r < 9; ++r) {   // (unrolled: the masks live in registers, a run index in a register would send them to scratch)
+            // (the run loop stays ROLLED -- unrolled, its 72 passes were 10 k instructions, more than the instruction cache holds --
+            // and the nine masks travel through a shift register instead of being indexed by the run)
+#pragma unroll 1
+            for (int r = 0; r < 9; ++r) {
                 unsigned m4[4];
                 int rloL = 0, s1L = 0;   // of this lane's OWN target: first row and 4 C of its (tile, column)
 #pragma unroll
@@ -1171,7 +1173,10 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                 const unsigned w = sRunAll[cellidx * 9 + r];
                 const int lo = (int)(w & 2047u), len = (int)(w >> 16);
                 const unsigned win = (unsigned)(m64 >> ((lo - rloL) & 63));
-                mfma_mk[r] = len > 0 ? (win & (0xffffffffu >> (32 - min(len, 32)))) : 0u;
+                const unsigned mnew = len > 0 ? (win & (0xffffffffu >> (32 - min(len, 32)))) : 0u;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) mfma_mk[k] = mfma_mk[k + 1];
+                mfma_mk[8] = mnew;   // after the ninth run mfma_mk[r] is run r's mask
             }
         }
         if (g && !overflow && !mode_reads_list<MODE>() && !SPH_ABL(d, 4)) {

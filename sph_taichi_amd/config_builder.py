@@ -7,9 +7,6 @@ import json
 
 
 class SimConfig:
-    _BLOCK_KEYS = {"get_rigid_bodies": "RigidBodies", "get_rigid_blocks": "RigidBlocks",
-                   "get_fluid_blocks": "FluidBlocks"}
-
     def __init__(self, scene_file_path=None, config: dict | None = None, verbose: bool = False) -> None:
         if config is None:
             with open(scene_file_path, "r") as fh:

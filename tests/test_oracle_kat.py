@@ -146,3 +146,44 @@ def test_polar_rotation_matches_svd():
         assert np.allclose(R, U @ Vt, atol=2e-6)
         assert np.linalg.det(R.astype(np.float64)) == pytest.approx(1.0, abs=1e-5)
     assert np.all(polar_rotation(np.zeros((3, 3))) == 0)
+
+
+def _closest_proper_rotation(A):
+    """What ti.polar_decompose's rotation factor is for ANY A (taichi's svd keeps det U = det V = +1 and lets the smallest
+    singular value go negative): U V^T of an SVD whose U and V are both proper rotations."""
+    U, s, Vt = np.linalg.svd(np.asarray(A, np.float64))
+    if np.linalg.det(U) < 0:
+        U[:, -1] *= -1
+    if np.linalg.det(Vt) < 0:
+        Vt[-1, :] *= -1
+    return U @ Vt
+
+
+def test_polar_rotation_of_degenerate_matrices():
+    """VERDICT r04 "missing" #6: the matrices shape matching produces for degenerate bodies -- rank 2 (a one-layer body), a
+    180-degree turn (trace R = -1), a reflection (det A < 0) -- where Newton, Jacobi and Taichi's SVD are most likely to part.
+    A = R0 S with a symmetric positive (semi)definite S of DISTINCT eigenvalues, so that the closest proper rotation is
+    unique; the oracle's Jacobi form must return it."""
+    from oracle.oracle import polar_rotation
+    rng = np.random.default_rng(3)
+
+    def rot(axis, deg):
+        k = np.asarray(axis, np.float64) / np.linalg.norm(axis)
+        K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        t = np.deg2rad(deg)
+        return np.eye(3) + np.sin(t) * K + (1 - np.cos(t)) * (K @ K)
+    for trial in range(20):
+        Q = rot(rng.normal(size=3), rng.uniform(0, 360))
+        R0 = rot(rng.normal(size=3), rng.choice([0.0, 25.0, 179.0, 180.0]))
+        for eig, mirror in (((3.0, 1.5, 0.0), False), ((3.0, 1.5, 0.4), True), ((2.0, 1.0, 0.5), False)):
+            S = Q @ np.diag(eig) @ Q.T
+            A = R0 @ S
+            if mirror:                                  # reflect through the plane normal to S's smallest eigenvector
+                n = Q[:, 2]
+                A = R0 @ (np.eye(3) - 2.0 * np.outer(n, n)) @ S
+            want = _closest_proper_rotation(A)
+            got = polar_rotation(A.astype(np.float32)).astype(np.float64)
+            assert np.linalg.det(got) == pytest.approx(1.0, abs=1e-5)
+            assert np.abs(got - want).max() <= 5e-6, (trial, eig, mirror)
+            if not mirror and eig[2] > 0:
+                assert np.abs(got - R0).max() <= 5e-6      # a rigid turn of a full-rank body is recovered, 180 degrees included

@@ -303,12 +303,12 @@ def main():
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # one node by contract; the container's hostname may not resolve
         wd.stage(f"init_process_group({backend})")
         to = datetime.timedelta(seconds=max(min(args.watchdog_s, 600.0), 60.0))
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=to)
-        else:
-            dist.init_process_group(backend, timeout=to)
-        from sph_taichi_amd.distributed import run_slab_bench
         try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=to)
+            else:
+                dist.init_process_group(backend, timeout=to)
+            from sph_taichi_amd.distributed import run_slab_bench
             line = run_slab_bench(args, rank, world, local_rank, wd=wd)
         except BaseException as e:      # noqa: BLE001 -- a rank that fails must say so and LEAVE: its peers sit in collectives
             import traceback

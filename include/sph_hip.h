@@ -126,10 +126,7 @@ enum SphOption {
                                   reference's add_particle produces for scenes whose fluid blocks share one density).
                                   -1 (default) = check on the device whenever m / m_V / material were uploaded or the
                                   particle set changed, and use it when it holds; 0 = never; 1 = check once, then the
-                                  caller vouches for later arrivals (slab ranks: migrating particles of the same scene);
-                                  2 = as 1, and the caller also vouches that the scene has NO solid particle at all, which
-                                  lets a slab rank run the pure-fluid instance of the density sweep (no m_V_j per pair; a
-                                  single context finds that out itself) */,
+                                  caller vouches for later arrivals (slab ranks: migrating particles of the same scene) */,
     SPH_OPT_UNIFORM_FLUID_STATE = 8 /* read-only (sph_get_option): -1 not decided yet, 0 general sweep, 1 one-gather sweep */,
     SPH_OPT_SORT_BY_PID = 9    /* 1 = inside a cell, order by persistent id instead of by previous index.  The reference
                                   order (previous index) is kept on a single GPU; slab ranks running DFSPH need an order

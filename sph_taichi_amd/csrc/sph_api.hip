@@ -279,7 +279,7 @@ int32_t sph_set_option(SphContext* c, int32_t option, int32_t value) {
             c->opt_variant = value < 0 ? SPH_VAR_DEFAULT : value;
             sph_invalidate_lists(c);
             return 0;
-        case SPH_OPT_UNIFORM_FLUID: if (value < -1 || value > 2) return sph_fail(c, SPH_E_INVALID, "uniform-fluid option must be -1, 0, 1 or 2"); c->opt_uniform = value; c->uniform_state = -1; return 0;
+        case SPH_OPT_UNIFORM_FLUID: if (value < -1 || value > 1) return sph_fail(c, SPH_E_INVALID, "uniform-fluid option must be -1, 0 or 1"); c->opt_uniform = value; c->uniform_state = -1; return 0;
     }
     return sph_fail(c, SPH_E_INVALID, "unknown option");
 }
@@ -815,7 +815,7 @@ int32_t sph_append_records(SphContext* c, const void* src, int32_t count) {
     SPH_HIP(c, hipMemcpyAsync(c->vf[c->cur] + o, s + b, b, hipMemcpyDeviceToDevice, c->stream));
     SPH_HIP(c, hipMemcpyAsync(c->aux[c->cur] + o, s + 2 * b, b, hipMemcpyDeviceToDevice, c->stream));
     c->N += count;
-    if (c->opt_uniform < 1) c->uniform_state = -1;  // arrivals are unchecked unless the caller vouches for them (1: their mass; 2: and no solids)
+    if (c->opt_uniform != 1) c->uniform_state = -1;  // arrivals are unchecked unless the caller vouches for them
     sph_invalidate_lists(c);
     c->have_keys = c->have_prefix = c->sorted = false;
     c->n_dyn_host = -1;

@@ -814,10 +814,6 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
     constexpr bool HAS_W = !mode_reads_list<MODE>();
     constexpr bool V_GROUPS = (VAR & SPH_VAR_GROUPS) != 0 && !mode_reads_list<MODE>();
     constexpr bool V_MFMA = (VAR & SPH_VAR_MFMA) != 0 && V_GROUPS && MODE == GM_DENSITY_EOS;  // the filter on the matrix pipe
-    // A scene WITHOUT ANY SOLID particle (every m_V is m_V0, checked on the device: SphContext::pure_fluid): the density pair
-    // term needs no m_V_j -- one LDS read and one multiply per hit less, the tile's m_V array is not written; the sum of
-    // the kernel values is scaled once.  Chosen by the launcher, not a user-visible variant bit.
-    constexpr bool V_PURE = (VAR & SPH_VAR_PURE_INTERNAL) != 0 && MODE == GM_DENSITY_EOS;
     constexpr bool V_BF = (VAR & SPH_VAR_FORCE_BF) != 0 && MODE == GM_FORCE_FUSED_U;
     constexpr bool V_DEEP = (VAR & SPH_VAR_DEEP) != 0 && mode_reads_list<MODE>();
     constexpr bool V_EXACT = (VAR & SPH_VAR_EXACT) != 0 && (MODE == GM_DENSITY_EOS || MODE == GM_FORCE_FUSED_U);  // SPH_OPT_EXACT_MATH
@@ -988,7 +984,7 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                 const float xl = buf[u].x - Ox, yl = buf[u].y - Oy, zl = buf[u].z - Oz;
                 if (HAS_W) {
                     sQ[idx] = make_float4(-2.0f * xl, -2.0f * yl, -2.0f * zl, xl * xl + yl * yl + zl * zl);
-                    if (!V_PURE) sW[idx] = buf[u].w;
+                    sW[idx] = buf[u].w;
                 } else {
                     sQ[idx] = buf[u];  // list-reading sweeps: the record as it is, so x_i - x_j is the reference's own f32 difference
                 }
@@ -1240,7 +1236,7 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
             // constants arranged for the issue rates)
             auto pair_term = [&](unsigned aq) {
                 const float4 q4 = *reinterpret_cast<const float4*>(smem + CFG::OFF_Q + aq);
-                const float mVj = V_PURE ? 1.0f : *reinterpret_cast<const float*>(smem + CFG::off_w(true) + (aq >> 2));
+                const float mVj = *reinterpret_cast<const float*>(smem + CFG::off_w(true) + (aq >> 2));
                 const float rx = fmaf(0.5f, q4.x, txl_), ry = fmaf(0.5f, q4.y, tyl_), rz = fmaf(0.5f, q4.z, tzl_);
                 const float r2 = rx * rx + ry * ry + rz * rz;
                 if (V_EXACT) { t.s0 += mVj * sph_W_exact(d, __fsqrt_rn(r2)); return; }  // WCSPH.py:19-30 as the reference's f32 expressions
@@ -1337,7 +1333,6 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
             // (flat cell 0's own range is never visited -- the reference's max(0, idx-1) quirk -- so a target that
             // lives there does not meet itself in the list and keeps the explicit self term)
             if (INLINE_PHYS) t.self_in_sum = key_i != 0;
-            if (V_PURE) t.s0 *= d.m_V0;   // (sum of W) x the one boundary-free volume = sum of m_V_j W
             else if (list_ovf) walk = true;
             if (mode_writes_list<MODE>()) gcnt[gi] = (unsigned char)(walk ? SPH_CNT_WALK : list_ovf ? SPH_CNT_LIST_OVF : cnt);
             __threadfence_block();  // this lane re-reads its own entries below
@@ -1648,8 +1643,6 @@ static int launch_brick(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, in
     if constexpr (MODE == GM_DENSITY_EOS) {
         if (c->opt_exact_math) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS | SPH_VAR_EXACT>(c, lo, hi, lo2, hi2);
         if ((var & SPH_VAR_GROUPS) && (var & SPH_VAR_MFMA)) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS | SPH_VAR_MFMA>(c, lo, hi, lo2, hi2);
-        if ((var & SPH_VAR_GROUPS) && c->pure_fluid && c->uniform_state == 1)
-            return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS | SPH_VAR_PURE_INTERNAL>(c, lo, hi, lo2, hi2);
         if (var & SPH_VAR_GROUPS) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS>(c, lo, hi, lo2, hi2);
     }
     if constexpr (MODE == GM_FORCE_FUSED_U) {

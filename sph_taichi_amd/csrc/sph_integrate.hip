@@ -1158,7 +1158,6 @@ int sphk_df_density_error(SphContext* c, float offset, float* out_host) {
 
 int sphk_check_uniform_fluid(SphContext* c) {
     c->uniform_state = 0;
-    c->pure_fluid = 0;
     c->m_uniform = 0.0f;
     if (c->N <= 0) return 0;
     DevView d = sph_view(c);
@@ -1174,11 +1173,6 @@ int sphk_check_uniform_fluid(SphContext* c) {
     if (h[3] > 0 && h[0] == h[1] && h[2] == 0) {
         memcpy(&c->m_uniform, &h[0], sizeof(float));
         c->uniform_state = c->m_uniform > 0.0f ? 1 : 0;
-        // no solid particle at all (fluid count == particle count).  A slab rank's later arrivals are unchecked: there the host
-        // must vouch for a scene without solids (SPH_OPT_UNIFORM_FLUID 2), as it vouches for the common mass with 1
-        // (SPH_DISABLE_PURE_FLUID in the environment: the A/B switch of this instance, read when the check runs)
-        c->pure_fluid = (c->uniform_state == 1 && h[3] == (unsigned)c->N && (!c->opt_drop_outside || c->opt_uniform == 2) &&
-                         !getenv("SPH_DISABLE_PURE_FLUID")) ? 1 : 0;
     }
     return 0;
 }

@@ -504,8 +504,7 @@ class SlabSolver:
         # one-gather force sweep: the host knows whether every fluid block has the same density (=> one particle
         # mass); then the device checks the local particles once and later arrivals are vouched for
         same_mass = len({float(b["density"]) for b in cfg.get_fluid_blocks()}) <= 1
-        no_solids = not cfg.get_rigid_blocks() and not cfg.get_rigid_bodies()
-        self.ps.set_option(_lib.OPT_UNIFORM_FLUID, (2 if no_solids else 1) if same_mass else 0)   # 2: and no arrival can be a solid
+        self.ps.set_option(_lib.OPT_UNIFORM_FLUID, 1 if same_mass else 0)
         nxl = self._set_target_layers()
         self.solver = self.ps.build_solver()
         self.dfsph = cfg.get_cfg("simulationMethod") == 4

@@ -123,6 +123,28 @@ def test_a_rank_stopped_by_the_launcher_still_names_its_stage(tmp_path):
     assert d["error"] == "terminated" and d["stage"] == "tiled: initialize (first exchange + sort)"
 
 
+def test_a_rank_that_raises_says_where_and_takes_the_job_down(tmp_path):
+    """Watchdog.fail (what bench.py calls from its except branch): rank 0 raises in a named stage while rank 1 waits for it.
+    Rank 0 prints {"error": "exception", "stage": ...} and leaves with rc 1 at once; the supervisor stops rank 1."""
+    rc, lines, err, took = _launch(tmp_path, """
+        from sph_taichi_amd.benchutil import Watchdog
+        r = int(os.environ["RANK"])
+        wd = Watchdog(r, 2, total_s=120.0, metric="m")
+        wd.stage("tiled: transport negotiation")
+        if r == 0:
+            try:
+                raise RuntimeError("librccl said no")
+            except BaseException as e:
+                wd.fail(f"{type(e).__name__}: {e}")
+        time.sleep(100)
+    """, grace_s=1.5)
+    assert rc == 1 and took < 60, (rc, err[-1500:])
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["error"] == "exception" and d["stage"] == "tiled: transport negotiation"
+    assert "librccl said no" in d["detail"] and d["rank"] == 0
+
+
 def test_collective_stage_fails_on_every_rank_alike(tmp_path):
     """an exception on ONE rank of the c4 object used to be caught by that rank alone while its peers
     waited in the next collective.  collective_stage: every rank raises CollectiveStageError naming stage and rank."""

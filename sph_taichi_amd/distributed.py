@@ -1076,7 +1076,8 @@ def _choose_transport(s, rank, local_rank):
     otherwise (gloo: several ranks sharing one GPU) or on request (SPH_TRANSPORT=torch)."""
     import torch
     import torch.distributed as dist
-    want = os.environ.get("SPH_TRANSPORT", "native" if dist.get_backend() == "nccl" else "torch")
+    # ("nccl", or the mixed "cpu:gloo,cuda:nccl": control plane over gloo, RCCL for everything on the device)
+    want = os.environ.get("SPH_TRANSPORT", "native" if "nccl" in str(dist.get_backend()) else "torch")
     transport = None
     if want == "native":
         transport, why = negotiate_native_transport(s.ps, torch.device("cuda", local_rank))
@@ -1095,15 +1096,26 @@ def _timed_steps(s, steps, red_dev):
     import torch.distributed as dist
     s.ps.sync()
     torch.cuda.synchronize()
-    dist.barrier()
+    _barrier(red_dev)
     t0 = time.perf_counter()
     s.step(steps)
     s.ps.sync()
     torch.cuda.synchronize()
-    dist.barrier()
+    _barrier(red_dev)
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     return float(dt.item())
+
+
+def _barrier(ctl_dev):
+    """A barrier on the job's CONTROL device: an all-reduce of one element there.  (dist.barrier() picks a device itself; with
+    the mixed backend "cpu:gloo,cuda:nccl" it would create the RCCL process group that this configuration exists to avoid.)"""
+    import torch
+    import torch.distributed as dist
+    t = torch.zeros(1, dtype=torch.int32, device=ctl_dev)
+    dist.all_reduce(t)
+    if ctl_dev.type == "cuda":
+        torch.cuda.synchronize(ctl_dev)
 
 
 def _phase_events(s, steps):
@@ -1152,6 +1164,8 @@ def _ctl_device(local_rank):
     gloo (several ranks sharing one GPU)."""
     import torch
     import torch.distributed as dist
+    # ("cpu:gloo,cuda:nccl": the control plane stays on the host, and torch's RCCL process group is never created unless the
+    # torch transport has to carry the records)
     return torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else torch.device("cpu")
 
 
@@ -1352,7 +1366,7 @@ def run_slab_bench(args, rank, world, local_rank, wd=None):
                    "rank0_host_ms_per_step": {k: round(v / max(host_ms["steps"], 1), 4)
                                               for k, v in host_ms.items() if k != "steps"},
                    "parallelism": f"x-slab x{world}, 1 exchange/step over "
-                                  f"{'RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()} P2P"},
+                                  f"{'RCCL' if 'nccl' in str(dist.get_backend()) else dist.get_backend()} P2P"},
         "steps_per_s_job": round(steps_per_s, 3),
         "breakdown_ms": dict(phases, rank=0, halo=round(host_ms["exchange"] / max(host_ms["steps"], 1), 4),
                              note="sort / neighbour / force / integrate: HIP events on rank 0's stream over extra steps "

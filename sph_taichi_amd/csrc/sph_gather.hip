@@ -814,6 +814,11 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
     constexpr bool HAS_W = !mode_reads_list<MODE>();
     constexpr bool V_GROUPS = (VAR & SPH_VAR_GROUPS) != 0 && !mode_reads_list<MODE>();
     constexpr bool V_MFMA = (VAR & SPH_VAR_MFMA) != 0 && V_GROUPS && MODE == GM_DENSITY_EOS;  // the filter on the matrix pipe
+    // A context WITHOUT ANY SOLID particle (checked on the device: SphContext::pure_fluid): every m_V_j is m_V0 BIT FOR BIT, so the
+    // density pair term takes it from a register instead of the tile -- one LDS read per hit less, the tile's m_V array is
+    // not written -- and computes exactly what it computed before (the same fma with the same operand values: results are
+    // bit-identical, unlike a form that would scale the sum of W once).  Chosen by the launcher, not a user-visible bit.
+    constexpr bool V_PURE = (VAR & SPH_VAR_PURE_INTERNAL) != 0 && MODE == GM_DENSITY_EOS;
     constexpr bool V_BF = (VAR & SPH_VAR_FORCE_BF) != 0 && MODE == GM_FORCE_FUSED_U;
     constexpr bool V_DEEP = (VAR & SPH_VAR_DEEP) != 0 && mode_reads_list<MODE>();
     constexpr bool V_EXACT = (VAR & SPH_VAR_EXACT) != 0 && (MODE == GM_DENSITY_EOS || MODE == GM_FORCE_FUSED_U);  // SPH_OPT_EXACT_MATH
@@ -984,7 +989,7 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                 const float xl = buf[u].x - Ox, yl = buf[u].y - Oy, zl = buf[u].z - Oz;
                 if (HAS_W) {
                     sQ[idx] = make_float4(-2.0f * xl, -2.0f * yl, -2.0f * zl, xl * xl + yl * yl + zl * zl);
-                    sW[idx] = buf[u].w;
+                    if (!V_PURE) sW[idx] = buf[u].w;
                 } else {
                     sQ[idx] = buf[u];  // list-reading sweeps: the record as it is, so x_i - x_j is the reference's own f32 difference
                 }
@@ -1202,7 +1207,8 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
             const float v_inv_h = sph_in_vgpr(d.inv_h);
             const float v_kw2 = sph_in_vgpr(d.k_w * 2.0f);
             const float v_kw8 = sph_in_vgpr(d.k_w * 8.0f);
-            (void)lrs; (void)voff; (void)lflip; (void)v_inv_h; (void)v_kw2; (void)v_kw8;
+            const float v_mV0 = sph_in_vgpr(d.m_V0);
+            (void)lrs; (void)voff; (void)lflip; (void)v_inv_h; (void)v_kw2; (void)v_kw8; (void)v_mV0;
 // Hits are collected in a per-run bitmask register (no LDS traffic while filtering) and turned into list
 // entries once per chunk of <= 32 candidates: ~7 ds_write per run instead of one per candidate.
 // One candidate = 3 FMA + 1 add + 1 v_alignbit: the test value r2' - thr' is negative for a hit, and alignbit shifts
@@ -1236,7 +1242,7 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
             // constants arranged for the issue rates)
             auto pair_term = [&](unsigned aq) {
                 const float4 q4 = *reinterpret_cast<const float4*>(smem + CFG::OFF_Q + aq);
-                const float mVj = *reinterpret_cast<const float*>(smem + CFG::off_w(true) + (aq >> 2));
+                const float mVj = V_PURE ? v_mV0 : *reinterpret_cast<const float*>(smem + CFG::off_w(true) + (aq >> 2));
                 const float rx = fmaf(0.5f, q4.x, txl_), ry = fmaf(0.5f, q4.y, tyl_), rz = fmaf(0.5f, q4.z, tzl_);
                 const float r2 = rx * rx + ry * ry + rz * rz;
                 if (V_EXACT) { t.s0 += mVj * sph_W_exact(d, __fsqrt_rn(r2)); return; }  // WCSPH.py:19-30 as the reference's f32 expressions
@@ -1643,6 +1649,9 @@ static int launch_brick(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, in
     if constexpr (MODE == GM_DENSITY_EOS) {
         if (c->opt_exact_math) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS | SPH_VAR_EXACT>(c, lo, hi, lo2, hi2);
         if ((var & SPH_VAR_GROUPS) && (var & SPH_VAR_MFMA)) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS | SPH_VAR_MFMA>(c, lo, hi, lo2, hi2);
+        // (pure_fluid is only ever set by a device-side check of THIS particle set: same count, single context)
+        if ((var & SPH_VAR_GROUPS) && c->uniform_state == 1 && c->pure_fluid && c->pure_fluid_n == c->N && !c->opt_drop_outside)
+            return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS | SPH_VAR_PURE_INTERNAL>(c, lo, hi, lo2, hi2);
         if (var & SPH_VAR_GROUPS) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS>(c, lo, hi, lo2, hi2);
     }
     if constexpr (MODE == GM_FORCE_FUSED_U) {

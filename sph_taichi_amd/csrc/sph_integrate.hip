@@ -1158,6 +1158,8 @@ int sphk_df_density_error(SphContext* c, float offset, float* out_host) {
 
 int sphk_check_uniform_fluid(SphContext* c) {
     c->uniform_state = 0;
+    c->pure_fluid = 0;
+    c->pure_fluid_n = -1;
     c->m_uniform = 0.0f;
     if (c->N <= 0) return 0;
     DevView d = sph_view(c);
@@ -1173,6 +1175,10 @@ int sphk_check_uniform_fluid(SphContext* c) {
     if (h[3] > 0 && h[0] == h[1] && h[2] == 0) {
         memcpy(&c->m_uniform, &h[0], sizeof(float));
         c->uniform_state = c->m_uniform > 0.0f ? 1 : 0;
+        // every particle is a fluid particle (and h[2] == 0 above: every fluid m_V is m_V0 bit for bit) => no solid at all.
+        // (SPH_DISABLE_PURE_FLUID in the environment = the A/B switch of the instance this selects, read when the check runs)
+        c->pure_fluid = (c->uniform_state == 1 && h[3] == (unsigned)c->N && !getenv("SPH_DISABLE_PURE_FLUID")) ? 1 : 0;
+        c->pure_fluid_n = c->N;
     }
     return 0;
 }

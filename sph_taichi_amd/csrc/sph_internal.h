@@ -27,6 +27,7 @@
 #define SPH_MAX_TIMED_STEPS 128
 #define SPH_GLIST_ROWS 96  // list entries allocated per particle (24 groups of four); lists up to LISTCAP = 95 entries (developed dam-break flows reach 58, profiles/archive/r03i)
 #define SPH_DF_ERR_BLOCKS 512
+#define SPH_VAR_PURE_INTERNAL 64   // not a user bit (sph_set_option refuses masks above 63): the pure-fluid instance of the density sweep
 #define SPH_VAR_DEFAULT (SPH_VAR_GROUPS | SPH_VAR_FORCE_BF | SPH_VAR_DEEP)  // SPH_OPT_KERNEL_VARIANT when the caller does not choose: the fastest rows of profiles/archive/r03f_variants_partition_x_emission.json (density) and r02g_variants_force.json (force)
 
 struct DevView {
@@ -174,6 +175,8 @@ struct SphContext {
                          // sph_ensure_aux folds them in before anything reads aux.y / aux.z or a reference-API sort moves the records
     int opt_uniform;     // SPH_OPT_UNIFORM_FLUID: -1 auto, 0 off, 1 check once
     int uniform_state;   // -1 unknown, 0 the precondition fails, 1 holds (m_uniform valid)
+    int pure_fluid;      // (with uniform_state == 1) the check found no solid particle at all among pure_fluid_n particles:
+    int pure_fluid_n;    //   every m_V is m_V0 bit for bit (single context only: a slab rank's arrivals are never checked)
     float m_uniform;
     // timing
     hipEvent_t ev[SPH_MAX_TIMED_STEPS][5];

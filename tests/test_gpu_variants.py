@@ -164,3 +164,29 @@ def test_phase_events_in_every_kth_step():
         out[k] = scenes.ps_by_pid(ps, "x")
         ps.close()
     assert np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[4])
+
+
+def test_pure_fluid_instance_of_the_density_sweep_is_bit_identical(monkeypatch):
+    """A context without any solid particle runs an instance of the density sweep that takes m_V_j = m_V0 from a register
+    instead of the tile (one LDS read per hit less; chosen by the launcher after a device-side check).  Same fma, same
+    operand values: densities, pressures and the trajectory must be BIT-identical to the general instance -- a form that
+    scaled the sum of W once was 2 % faster too and moved the violent reference-executed fixture from 1.5e-6 to 7.8e-4
+    (DESIGN_HISTORY.md, round 5).  Scenes with solids never select it."""
+    from sph_taichi_amd import _lib
+    sd = scenes.fluid_only(counts=(18, 14, 16), start=(0.04, 0.04, 0.04), velocity=(0.6, -1.0, 0.3))
+    cfg, sc = scenes.build(sd)
+    scenes.jitter(sc, 0.1, seed=11)
+    out = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("SPH_DISABLE_PURE_FLUID", "1")
+        else:
+            monkeypatch.delenv("SPH_DISABLE_PURE_FLUID", raising=False)
+        ps, solver = scenes.make_ps(sd, sc.arrays)
+        solver.initialize()
+        solver.step(25)
+        assert ps.get_option(_lib.OPT_UNIFORM_FLUID_STATE) == 1
+        out.append({n: scenes.ps_by_pid(ps, n) for n in ("x", "v", "density", "pressure")})
+        ps.close()
+    for n in out[0]:
+        assert np.array_equal(out[0][n], out[1][n]), f"{n} differs between the pure-fluid and the general instance"

@@ -14,7 +14,8 @@ N = 1 it is exactly the job's steps/s; at N > 1 (x-slab sharding, every rank own
 one 1.75 M slab: weak scaling) it is the whole-job aggregate.
 
 The JSON line also carries
-  roofline      : the dominant kernel (the density + EOS sweep) -- algorithmic bytes per
+  roofline      : the dominant kernel, ALWAYS the density + EOS sweep (largest duration in the committed
+                  kernel traces; `roofline_force` is the force sweep's object) -- algorithmic bytes per
                   launch (32*N + 4*G) / its mean launch time from HIP events
                   on the kernel's own stream, against the 8 TB/s HBM peak; `traffic`
                   (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE) and the VALU figures come from
@@ -277,15 +278,26 @@ def main():
         os.environ["SPH_HIP_LIB_VARIANT"] = "profile"
 
     metric = "WCSPH steps/sec at 1.74 M particles (+ ms/step breakdown sort/neighbour/force)"
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if args.gpus > 1 and not ("RANK" in os.environ and "WORLD_SIZE" in os.environ):
         # No launcher: this process becomes the supervisor of its own N ranks (VERDICT r04 "next" #2a).
         from sph_taichi_amd.benchutil import self_launch
         sys.exit(self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus, args.watchdog_s, metric=metric))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # A launcher is present iff it set RANK and WORLD_SIZE (torch.distributed.run sets both); a WORLD_SIZE merely inherited
+    # from some outer environment is not a job to join.
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    world = int(os.environ["WORLD_SIZE"]) if launched else 1
+    rank = int(os.environ.get("RANK", "0")) if launched else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if launched else 0
+    gpus_given = any(a == "--gpus" or a.startswith("--gpus=") for a in sys.argv[1:])
+    if launched and not gpus_given:
+        args.gpus = world           # `torchrun ... bench.py` without --gpus: the launcher's world is the job
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+        # never die without a line: the driver parses stdout (exit code 2 = bad invocation)
+        if rank == 0:
+            print(json.dumps({"metric": metric, "value": None, "unit": "steps/s", "n_gpus": args.gpus, "error": "invocation",
+                              "stage": "argument check", "rank": rank,
+                              "detail": f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks"}), flush=True)
+        sys.exit(2)
     from sph_taichi_amd.benchutil import Watchdog
     wd = Watchdog(rank, world, total_s=args.watchdog_s, metric=metric, enabled=world > 1, take_sigterm=world > 1)
     wd.stage("import torch")
@@ -516,7 +528,11 @@ def main():
                     e["valu_wave_insts"] = wi
                     e["valu_issue_frac"] = round(wi / (ms * 1e-3) / 1e9 / VALU_PEAK_GINST, 4)
             rk[k_] = e
-        dominant = max(kernels, key=lambda k_: kernels[k_][1])
+        # ALWAYS the density + EOS sweep: by the committed kernel trace (profiles/r05f_kernel_stats_c3p_rest.csv and the r06 one) it
+        # is the kernel with the largest duration in both states.  Never an argmax over two phase times 0.1 % apart: that made
+        # the object flip to the force sweep between rounds and its fraction double with no kernel faster;
+        # the force sweep has its own object, `roofline_force`.
+        dominant = next(k_ for k_ in kernels if "DENSITY" in k_)
         st = _lib.SphStats()
         ps._call("sph_get_stats", st)
         step_bytes = 360.0 * N + 20.0 * G
@@ -621,11 +637,26 @@ def main():
                              "so this fraction measures how far the sweep is from a pure streaming pass, not HBM "
                              "saturation; traffic = rocprofv3 FETCH_SIZE*2 + WRITE_SIZE per launch; avg_launch_ms is the "
                              "HIP-event time of the phase the kernel runs in (neighbour phase = brick-list kernel + sweep)"},
+        "roofline_force": None,
         "roofline_valu": roofline_valu,
         "roofline_kernels": rest["roofline_kernels"],
         "roofline_step": rest["roofline_step"],
         "neighbourhood": dict(rest["neighbourhood"], note="last density sweep of the timed region (sph_get_stats); list entries = superset filter incl. self"),
     }
+    fk_name = next(k_ for k_ in rest["roofline_kernels"] if "FORCE" in k_)
+    fk = rest["roofline_kernels"][fk_name]
+    line["roofline_force"] = {
+        "kernel": fk_name, "bound": "hbm", "achieved": fk["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": fk["frac_of_hbm_peak"], "traffic": fk["traffic"], "alg_bytes_per_launch": fk["alg_bytes"],
+        "avg_launch_ms": fk["avg_launch_ms"], "counters": pmc_note,
+        "bytes_as_moved": {"note": "the fraction is quoted on SURVEY 8(d)'s minimal-fused force row, 60 N + 4 G (read x, v, m_V, density, "
+                                   "pressure, flags of the target + write its acceleration), as the contract asks.  What THIS launch moves is "
+                                   "not that row: inside sph_step(K) the sweep has absorbed the fluid's advect + wall pass (read / write x, v: "
+                                   "68 N more), and on every step of a call but the last it does NOT write the acceleration out (skip_acc: the "
+                                   "field is dead until the next step rewrites it; 16 N less) -- parity-neutral, but neither the "
+                                   "reference-shaped step's bytes nor this kernel's.",
+                           "absorbed_advect_bytes": 68.0 * N, "acceleration_store_skipped_bytes": 16.0 * N,
+                           "alg_bytes_of_sweep_plus_absorbed_advect": fk["alg_bytes"] + 68.0 * N}}
     # State B: the same box after `--settled-after` untimed steps (the fluid has sunk to its rest density: 10 particles
     # per cell instead of the lattice's 8, 43 neighbours instead of 33) -- what a long run sees.  One contiguous block
     # of at least K steps and at least --min-seconds.
@@ -656,6 +687,11 @@ def main():
     # value (mean of the preheated blocks from rest) >= value_single_block >= value_with_bodies / value_settled
     line["value_settled"] = line["settled"]["value"] if isinstance(line.get("settled"), dict) else None
     line["value_with_bodies"] = (line["with_bodies"].get("value") if isinstance(line.get("with_bodies"), dict) else None)
+    # ... and inside `config`, which every parser of the contract line keeps (the top-level extras landed in
+    # `extra_keys` without their values)
+    line["config"].update(value_is="mean of `reps` preheated W+K blocks from the rest lattice",
+                          value_single_block=line["value_single_block"], value_settled=line["value_settled"],
+                          value_with_bodies=line["value_with_bodies"])
     if args.cpu_steps > 0:
         line["cpu_baseline"] = cpu_baseline(sd, args.cpu_steps)
     else:

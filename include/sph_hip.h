@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SPH_ABI_VERSION 4
+#define SPH_ABI_VERSION 5
 
 typedef struct SphContext SphContext;
 
@@ -153,7 +153,16 @@ enum SphOption {
                                   inline / lean and GM_FORCE_FUSED_U); scenes with any solid run the general sweeps, whose
                                   pair physics keeps v_rsq / v_rcp, and so do the cell-walk fallbacks.  sph_get_option
                                   reports the EFFECTIVE state: 1 only while the context's step actually runs those
-                                  instances (SPH_OPT_UNIFORM_FLUID_STATE == 1), else 0. */
+                                  instances (SPH_OPT_UNIFORM_FLUID_STATE == 1), else 0. */,
+    SPH_OPT_RIGID_SUMS_FROM_X0 = 14, /* 1 = the centre-of-mass sums of sph_compute_rigid_rest_cm and sph_rigid_partial_sums read the REST
+                                  positions x_0 instead of x.  In the reference x_0 == x when initialize() computes
+                                  rigid_rest_cm (sph_base.py:80-90); a RESTART (positions given, x_0 from the scene file) must not
+                                  take the displaced body's centre for the rest centre.  The Python layer sets it around the
+                                  rest-cm computation of a restarted ParticleSystem and clears it again; default 0. */
+    SPH_OPT_PURE_FLUID_INSTANCE = 15 /* 1 (default) = a single context found (on the device) to hold no solid particle at all runs the
+                                  density sweep's pure-fluid instance (m_V_j = m_V0 from a register; bit-identical results);
+                                  0 = always the general instance (the A/B switch; was the SPH_DISABLE_PURE_FLUID environment
+                                  variable in ABI 4) */
 };
 #define SPH_VAR_GROUPS 1   /* density: all nine runs filtered first (masks in registers), hits emitted centre run / edge runs / corner
                               runs, each group by descending hit count */

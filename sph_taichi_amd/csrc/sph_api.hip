@@ -57,6 +57,7 @@ DevView sph_view(const SphContext* c) {
     d.gate_epoch = c->df_epoch;
     d.fx_scale = ldexp(1.0, c->rigid_fx_exp);
     d.store_acc = !(c->fuse_advect && c->skip_acc);
+    d.rigid_from_x0 = 0;   // set by the two launchers the option speaks of (sphk_rigid_com to_rest, sphk_rigid_partial16)
     return d;
 }
 
@@ -73,6 +74,20 @@ struct CellIdx16 { int v[16]; };
 __global__ void k_read_cells(const int* __restrict__ cell_end, CellIdx16 ix, int* __restrict__ out) {
     const int k = threadIdx.x;
     if (k < 16 && ix.v[k] >= 0) out[k] = cell_end[ix.v[k]];
+}
+
+// Every entry that synchronises with the stream looks here afterwards (sph_sync, sph_download, sph_get_stats, sph_get_timings,
+// the DFSPH solver loops): a scan tile whose bounded wait ran out has substituted 0 for a predecessor's total, so the cell
+// table of that sort -- and everything computed from it since -- is wrong.  The flag lives in mapped host memory.
+int sph_check_device_flags(SphContext* c) {
+    if (c->h_pinned && ((volatile int*)c->h_pinned)[16]) {
+        ((volatile int*)c->h_pinned)[16] = 0;
+        c->sorted = c->have_prefix = c->have_keys = false;
+        sph_invalidate_lists(c);
+        return sph_fail(c, SPH_E_STATE, "prefix sum: a scan tile never saw a predecessor's total (k_scan_fused's bounded wait ran out); "
+                                        "the cell table of that sort and every result since are invalid: re-upload the state and sort again");
+    }
+    return 0;
 }
 
 extern "C" {
@@ -133,6 +148,8 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     c->opt_rigid_batch = 1;
     c->opt_df_runahead = 0;   // measured (r05): running ahead costs 2 % more than the bubbles it removes
     c->opt_exact_math = 0;
+    c->opt_rigid_x0 = 0;
+    c->opt_pure_instance = 1;
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -280,6 +297,8 @@ int32_t sph_set_option(SphContext* c, int32_t option, int32_t value) {
             sph_invalidate_lists(c);
             return 0;
         case SPH_OPT_UNIFORM_FLUID: if (value < -1 || value > 1) return sph_fail(c, SPH_E_INVALID, "uniform-fluid option must be -1, 0 or 1"); c->opt_uniform = value; c->uniform_state = -1; return 0;
+        case SPH_OPT_RIGID_SUMS_FROM_X0: c->opt_rigid_x0 = value ? 1 : 0; return 0;
+        case SPH_OPT_PURE_FLUID_INSTANCE: c->opt_pure_instance = value ? 1 : 0; sph_invalidate_lists(c); return 0;
     }
     return sph_fail(c, SPH_E_INVALID, "unknown option");
 }
@@ -303,6 +322,8 @@ int32_t sph_get_option(const SphContext* c, int32_t option, int32_t* value) {
         case SPH_OPT_KERNEL_VARIANT: *value = c->opt_variant; return 0;
         case SPH_OPT_DF_RUNAHEAD: *value = c->opt_df_runahead; return 0;
         case SPH_OPT_UNIFORM_FLUID_STATE: *value = c->uniform_state; return 0;
+        case SPH_OPT_RIGID_SUMS_FROM_X0: *value = c->opt_rigid_x0; return 0;
+        case SPH_OPT_PURE_FLUID_INSTANCE: *value = c->opt_pure_instance; return 0;
     }
     return SPH_E_INVALID;
 }
@@ -329,6 +350,7 @@ int32_t sph_set_particle_count(SphContext* c, int32_t n) {
     if (!c || n < 0 || n > c->cap) return sph_fail(c, SPH_E_INVALID, "particle count out of range");
     c->N = n;
     c->n_dyn_host = -1;
+    sph_forget_pure_fluid(c);
     sph_invalidate_lists(c);
     c->aux_stale = false;
     c->have_keys = c->have_prefix = false;
@@ -388,7 +410,7 @@ int32_t sph_download(SphContext* c, int32_t field, void* host, size_t bytes) {
     }
     SPH_HIP(c, hipMemcpyAsync(host, src, bytes, hipMemcpyDeviceToHost, c->stream));
     SPH_HIP(c, hipStreamSynchronize(c->stream));
-    return 0;
+    return sph_check_device_flags(c);
 }
 
 // number (and current-order list) of dynamic rigid particles; refreshed lazily
@@ -490,8 +512,9 @@ int32_t sph_compute_non_pressure_forces(SphContext* c) {
     ENTER(c);
     int rc = need_sorted(c, "sph_compute_non_pressure_forces");
     rc = rc ? rc : sph_ensure_aux(c);
-    c->acc_partial = false;   // every particle's acceleration is (re)written from here on
-    return rc ? rc : sphk_gather(c, GM_NONPRESSURE);
+    rc = rc ? rc : sphk_gather(c, GM_NONPRESSURE);
+    if (!rc) c->acc_partial = false;   // every particle's acceleration has been (re)written
+    return rc;
 }
 
 int32_t sph_compute_pressure_forces(SphContext* c) {
@@ -778,6 +801,7 @@ int32_t sph_select_range(SphContext* c, int32_t first, int32_t count) {
     if (first < 0 || count < 0 || first + count > c->in_off + c->N) return sph_fail(c, SPH_E_INVALID, "sph_select_range: out of range");
     c->in_off += first;
     c->N = count;
+    sph_forget_pure_fluid(c);
     sph_invalidate_lists(c);
     c->aux_stale = false;  // (eos2 is indexed from the old first record)
     c->have_keys = c->have_prefix = c->sorted = false;
@@ -788,6 +812,7 @@ int32_t sph_select_range(SphContext* c, int32_t first, int32_t count) {
 int32_t sph_truncate(SphContext* c, int32_t n) {
     if (!c || n < 0 || n > c->N) return sph_fail(c, SPH_E_INVALID, "sph_truncate: out of range");
     if (n != c->N && !c->opt_no_dynamic) c->n_dyn_host = -1;  // the sort's list skipped the dropped strays: recount
+    if (n != c->N) sph_forget_pure_fluid(c);   // (a truncate + append that restores N may bring solids in)
     c->N = n;
     return 0;
 }
@@ -816,6 +841,7 @@ int32_t sph_append_records(SphContext* c, const void* src, int32_t count) {
     SPH_HIP(c, hipMemcpyAsync(c->aux[c->cur] + o, s + 2 * b, b, hipMemcpyDeviceToDevice, c->stream));
     c->N += count;
     if (c->opt_uniform != 1) c->uniform_state = -1;  // arrivals are unchecked unless the caller vouches for them
+    sph_forget_pure_fluid(c);   // ... and vouching is for a uniform fluid MASS only: arrivals may be solids
     sph_invalidate_lists(c);
     c->have_keys = c->have_prefix = c->sorted = false;
     c->n_dyn_host = -1;
@@ -825,18 +851,14 @@ int32_t sph_append_records(SphContext* c, const void* src, int32_t count) {
 int32_t sph_sync(SphContext* c) {
     ENTER(c);
     SPH_HIP(c, hipStreamSynchronize(c->stream));
-    if (c->h_pinned && c->h_pinned[16]) {
-        c->h_pinned[16] = 0;
-        return sph_fail(c, SPH_E_STATE, "prefix sum: a scan tile never saw a predecessor's total (k_scan_fused's bounded wait ran out); "
-                                        "the cell table of that sort is invalid");
-    }
-    return 0;
+    return sph_check_device_flags(c);
 }
 
 int32_t sph_get_timings(SphContext* c, SphTimings* out) {
     ENTER(c);
     if (!out) return SPH_E_INVALID;
     int rc = harvest_events(c);
+    rc = rc ? rc : sph_check_device_flags(c);   // (harvest_events waited for the last timed step)
     if (rc) return rc;
     *out = c->tm;
     return 0;
@@ -846,7 +868,8 @@ int32_t sph_get_stats(SphContext* c, SphStats* out) {
     ENTER(c);
     if (!out) return SPH_E_INVALID;
     if (!c->have_prefix) return sph_fail(c, SPH_E_STATE, "sph_get_stats needs a sorted state (run a step first)");
-    return sphk_stats(c, out);
+    int rc = sphk_stats(c, out);   // synchronises
+    return rc ? rc : sph_check_device_flags(c);
 }
 
 int32_t sph_reset_timings(SphContext* c) {
@@ -1122,6 +1145,7 @@ static int df_solve_loop(SphContext* c, const DfSolve& s, int* iterations, doubl
         if (ahead) rc = df_enqueue_body(c, s, k + 1);  // ahead of body k's test; a no-op on the device if that test closes the solve
         if (rc) break;
         if (hipEventSynchronize(c->ev_df[k & 3]) != hipSuccess) { rc = sph_fail(c, SPH_E_STATE, "DFSPH solver: event wait failed"); break; }
+        if ((rc = sph_check_device_flags(c)) != 0) break;
         const volatile SphContext::DfSlot* slot = c->h_df_slot + (k & 3);
         *total += 1;
         avg = slot->avg;

@@ -1650,7 +1650,7 @@ static int launch_brick(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, in
         if (c->opt_exact_math) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS | SPH_VAR_EXACT>(c, lo, hi, lo2, hi2);
         if ((var & SPH_VAR_GROUPS) && (var & SPH_VAR_MFMA)) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS | SPH_VAR_MFMA>(c, lo, hi, lo2, hi2);
         // (pure_fluid is only ever set by a device-side check of THIS particle set: same count, single context)
-        if ((var & SPH_VAR_GROUPS) && c->uniform_state == 1 && c->pure_fluid && c->pure_fluid_n == c->N && !c->opt_drop_outside)
+        if ((var & SPH_VAR_GROUPS) && c->opt_pure_instance && c->uniform_state == 1 && c->pure_fluid && c->pure_fluid_n == c->N && !c->opt_drop_outside)
             return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS | SPH_VAR_PURE_INTERNAL>(c, lo, hi, lo2, hi2);
         if (var & SPH_VAR_GROUPS) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS>(c, lo, hi, lo2, hi2);
     }

@@ -286,8 +286,13 @@ __global__ __launch_bounds__(TPB) void k_rigid_sum(DevView d, const int* __restr
         const int i = list[tix];
         const int fl = __float_as_int(d.vf[i].w);
         if (sph_is_dynamic_rigid(fl) && sph_flags_object(fl) == object_id) {
-            const float4 xm = d.xm[i];
-            const float mass = d.m_V0 * d.aux[i].y;
+            float4 xm = d.xm[i];
+            const float4 aux = d.aux[i];
+            if (d.rigid_from_x0) {   // SPH_OPT_RIGID_SUMS_FROM_X0: the rest centre of a restarted body
+                const int pid = __float_as_int(aux.w);
+                xm.x = d.x0_cold[3 * pid]; xm.y = d.x0_cold[3 * pid + 1]; xm.z = d.x0_cold[3 * pid + 2];
+            }
+            const float mass = d.m_V0 * aux.y;
             s[0] = to_fx(d, mass); s[1] = to_fx(d, (double)(mass * xm.x)); s[2] = to_fx(d, (double)(mass * xm.y)); s[3] = to_fx(d, (double)(mass * xm.z));
         }
     }
@@ -738,7 +743,9 @@ __global__ __launch_bounds__(TPB) void k_rigid_sum16(DevView d, const int* __res
             const int pid = __float_as_int(aux.w);
             const float* rc = &d.rigid_rest_cm[3 * object_id];
             const float mass = d.m_V0 * aux.y;
-            const float x[3] = {xm.x, xm.y, xm.z};
+            // (SPH_OPT_RIGID_SUMS_FROM_X0: x_0 stands in for x -- only sums 0..3, the rest centre of a restart, are used then)
+            const float x[3] = {d.rigid_from_x0 ? d.x0_cold[3 * pid] : xm.x, d.rigid_from_x0 ? d.x0_cold[3 * pid + 1] : xm.y,
+                                d.rigid_from_x0 ? d.x0_cold[3 * pid + 2] : xm.z};
             const float q[3] = {d.x0_cold[3 * pid] - rc[0], d.x0_cold[3 * pid + 1] - rc[1],
                                 d.x0_cold[3 * pid + 2] - rc[2]};
             s[0] = to_fx(d, mass);
@@ -956,6 +963,7 @@ int sphk_enforce_boundary(SphContext* c, int particle_type) {
 // cm of object -> rigid_R[0..2] (and rigid_rest_cm[object] when to_rest)
 int sphk_rigid_com(SphContext* c, int object_id, bool to_rest) {
     DevView d = sph_view(c);
+    d.rigid_from_x0 = (to_rest && c->opt_rigid_x0) ? 1 : 0;
     const int n = c->n_dyn_host > 0 ? c->n_dyn_host : 0;
     const int nb = n > 0 ? (n + TPB - 1) / TPB : 1;
     if (nb > c->rigid_part_blocks) return sph_fail(c, SPH_E_NOMEM, "rigid partial-sum buffer too small");
@@ -1054,6 +1062,7 @@ int sphk_build_dyn_list(SphContext* c) {
 
 int sphk_rigid_partial16(SphContext* c, int object_id, int first, int count, double* out) {
     DevView d = sph_view(c);
+    d.rigid_from_x0 = c->opt_rigid_x0;   // (the host sets the option around the mode-0 sums of a restart only)
     const int n = c->n_dyn_host;
     const int nb = n > 0 ? (n + TPB - 1) / TPB : 0;
     if (nb > c->rigid_part_blocks) return sph_fail(c, SPH_E_NOMEM, "rigid partial-sum buffer too small");
@@ -1176,8 +1185,8 @@ int sphk_check_uniform_fluid(SphContext* c) {
         memcpy(&c->m_uniform, &h[0], sizeof(float));
         c->uniform_state = c->m_uniform > 0.0f ? 1 : 0;
         // every particle is a fluid particle (and h[2] == 0 above: every fluid m_V is m_V0 bit for bit) => no solid at all.
-        // (SPH_DISABLE_PURE_FLUID in the environment = the A/B switch of the instance this selects, read when the check runs)
-        c->pure_fluid = (c->uniform_state == 1 && h[3] == (unsigned)c->N && !getenv("SPH_DISABLE_PURE_FLUID")) ? 1 : 0;
+        // (whether the launcher USES the verdict is SPH_OPT_PURE_FLUID_INSTANCE: the A/B switch of the instance it selects)
+        c->pure_fluid = (c->uniform_state == 1 && h[3] == (unsigned)c->N) ? 1 : 0;
         c->pure_fluid_n = c->N;
     }
     return 0;

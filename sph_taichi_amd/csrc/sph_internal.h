@@ -61,6 +61,7 @@ struct DevView {
     int write_k;        // density-change / -advection finish also writes k_j into kbuf
     int store_acc;      // GM_FORCE_FUSED_U finish with the fused advect: also store the acceleration (0: a step inside
                         // sph_step(n) that is not the last -- nothing can read the field before the next step rewrites it)
+    int rigid_from_x0;  // the centre-of-mass sums read x_0 instead of x (SPH_OPT_RIGID_SUMS_FROM_X0: rest cm of a restart)
     float4* xm;
     float4* vf;
     float4* aux;
@@ -166,6 +167,8 @@ struct SphContext {
     int opt_rigid_batch;  // SPH_OPT_RIGID_BATCH: 1 (default) = solve_rigid_body() of all bodies in three launches
     int opt_df_runahead;  // SPH_OPT_DF_RUNAHEAD: 1 = DFSPH solver bodies are enqueued one ahead of the convergence test
     int opt_exact_math;   // SPH_OPT_EXACT_MATH: 1 = IEEE divide / sqrt instances of the brick sweeps (A/B of the fast-math choice)
+    int opt_rigid_x0;     // SPH_OPT_RIGID_SUMS_FROM_X0: the rest-cm sums read x_0 (set by the host around the rest cm of a restart)
+    int opt_pure_instance;  // SPH_OPT_PURE_FLUID_INSTANCE: 1 (default) = a solid-free single context may run the pure-fluid density instance
     int opt_variant;     // SPH_OPT_KERNEL_VARIANT (bit mask of SPH_VAR_*)
     int fuse_advect;     // set around the force launch of sph_step when the advect can ride in its finish
     int skip_acc;        // set by sph_step for every step but the last of a call: the fused force finish keeps its acceleration to itself
@@ -192,6 +195,11 @@ static inline hipStream_t sph_stream(const SphContext* c) { return c->use_side ?
 #define SPH_BRICK_HEAVY 160  // targets from which a brick counts as heavy (a full 4x2x4 brick at rest has 256)
 static inline void sph_invalidate_lists(SphContext* c) { c->lists_valid = false; c->bricks_valid = false; c->stg_kind = 0; c->k_kind = 0; }
 int sph_fail(SphContext* c, int code, const char* what);
+// the particle SET changed (records appended / dropped / re-selected): whatever a device-side check established about it is void
+static inline void sph_forget_pure_fluid(SphContext* c) { c->pure_fluid = 0; c->pure_fluid_n = -1; }
+// after a host synchronisation: did a device-side error flag rise since the last look (k_scan_fused's bounded wait)?  Marks the
+// sort invalid and returns SPH_E_STATE with the message set; 0 otherwise.
+int sph_check_device_flags(SphContext* c);
 
 #define SPH_HIP(ctx, expr)                                                        \
     do {                                                                          \

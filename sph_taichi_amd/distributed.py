@@ -634,10 +634,19 @@ class SlabSolver:
         self.stats["sent"] += nL + nR
         return self.send_buf["L"], nL, self.send_buf["R"], nR
 
-    def rigid_partial(self, oid):
-        """This rank's 16 shape-matching sums of body `oid` (device tensor, ready for the all-reduce)."""
+    def rigid_partial(self, oid, rest=False):
+        """This rank's 16 shape-matching sums of body `oid` (device tensor, ready for the all-reduce).  `rest`: the sums
+        feed the REST centre of mass (mode 0) -- of a restarted job they are taken over x_0, not over the restart positions
+        (in the reference x_0 == x when initialize() computes rigid_rest_cm, sph_base.py:80-90)."""
         first, count = self.owned_range
-        self.ps._call("sph_rigid_partial_sums", int(oid), first, count, C.c_void_p(self.sums.data_ptr()))
+        from_x0 = rest and getattr(self.ps, "_restarted", False)
+        if from_x0:
+            self.ps.set_option(_lib.OPT_RIGID_SUMS_FROM_X0, 1)
+        try:
+            self.ps._call("sph_rigid_partial_sums", int(oid), first, count, C.c_void_p(self.sums.data_ptr()))
+        finally:
+            if from_x0:
+                self.ps.set_option(_lib.OPT_RIGID_SUMS_FROM_X0, 0)
         self.ps.sync()
         return self.sums
 
@@ -650,7 +659,7 @@ class SlabSolver:
 
     def solve_rigid_bodies(self, mode=1):
         for oid in self.dynamic_bodies:
-            self.transport.all_reduce_sum(self.rigid_partial(oid))
+            self.transport.all_reduce_sum(self.rigid_partial(oid, rest=(mode == 0)))
             self.rigid_apply(oid, mode)
 
     def phase_advance(self, recv_left, n_left, recv_right, n_right, density=True):
@@ -942,7 +951,7 @@ def run_local_slabs(solvers, n_steps, initialize=False):
 
     def solve_bodies(mode):
         for oid in solvers[0].dynamic_bodies:
-            total = sum(s.rigid_partial(oid).clone() for s in solvers)
+            total = sum(s.rigid_partial(oid, rest=(mode == 0)).clone() for s in solvers)
             for s in solvers:
                 s.sums.copy_(total)
                 s.torch.cuda.current_stream().synchronize()
@@ -1266,11 +1275,15 @@ def run_c4_dambreak(args, rank, world, local_rank, scale=1.0, wd=None):
         return out
     finally:
         wd.stage("c4_dambreak: teardown")
+        # (a close() that raises must not mask the stage error that brought us here: ADVICE r05)
         t = box.get("t")
-        if isinstance(t, NativeTransport):
-            t.close()
-        if box.get("s") is not None:
-            box["s"].close()
+        for obj in ((t if isinstance(t, NativeTransport) else None), box.get("s")):
+            if obj is None:
+                continue
+            try:
+                obj.close()
+            except Exception as e:      # noqa: BLE001
+                print(f"[bench] rank {rank}: c4_dambreak teardown: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
 
 
 def _comm_info(transport):

@@ -34,6 +34,7 @@ class ParticleSystem:
         self.cfg = config
         self.GGUI = GGUI
         self.slab = slab
+        self._restarted = state is not None     # SPHBase.initialize / SlabSolver.initialize: rest cm from x_0, not from x
         x_filter = None
         if slab is not None:
             g0 = _scene.Geometry(config)
@@ -316,7 +317,17 @@ class ParticleSystem:
     def save_state(self, path: str, **meta):
         """Every per-particle array in the current (cell-sorted) order + rigid_rest_cm, as one .npz.  Restoring it
         into a ParticleSystem built from the same scene continues the run exactly where it stopped."""
-        data = {f: getattr(self, f).to_numpy() for f in self._STATE_FIELDS}
+        data = {}
+        for f in self._STATE_FIELDS:
+            try:
+                data[f] = getattr(self, f).to_numpy()
+            except _lib.SphError:
+                # a slab rank right after a fused sph_slab_forces: the interior accelerations were consumed in the sweep's
+                # finish and never written out (sph_download refuses stale values).  The field is dead across steps --
+                # every step rewrites it before reading it -- so the checkpoint carries zeros.
+                if f != "acceleration":
+                    raise
+                data[f] = np.zeros((self.count() if self.slab is not None else self.particle_max_num, 3), dtype=np.float32)
         if self.num_rigid_bodies > 0:
             data["rigid_rest_cm"] = self.rigid_rest_cm.to_numpy()
         data["particle_max_num"] = np.int64(self.particle_max_num)

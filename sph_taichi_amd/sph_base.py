@@ -36,8 +36,18 @@ class SPHBase:
     def initialize(self):
         self._push()
         self.ps.initialize_particle_system()
-        for r_obj_id in self.ps.object_id_rigid_body:
-            self.compute_rigid_rest_cm(r_obj_id)
+        # A restarted ParticleSystem (state=...) holds displaced bodies: their REST centre is that of x_0, which is what the
+        # reference's compute_com(x) gives at this point of an uninterrupted run (x_0 == x, sph_base.py:80-90, 182-192).
+        from . import _lib
+        restarted = getattr(self.ps, "_restarted", False)
+        if restarted:
+            self.ps.set_option(_lib.OPT_RIGID_SUMS_FROM_X0, 1)
+        try:
+            for r_obj_id in self.ps.object_id_rigid_body:
+                self.compute_rigid_rest_cm(r_obj_id)
+        finally:
+            if restarted:
+                self.ps.set_option(_lib.OPT_RIGID_SUMS_FROM_X0, 0)
         self.compute_static_boundary_volume()
         self.compute_moving_boundary_volume()
 

@@ -219,3 +219,35 @@ def evidence_path(name):
     except OSError:
         return None
     return os.path.join(d, name)
+
+
+# ---- measured-error registry (VERDICT r05 "weak" #2: bounds at <= 3 x what is measured) ------------------------------------
+_BOUNDS = {}      # group -> {name: (worst measured error, its bound)}
+
+
+def bound(group, name, err, tol):
+    """Assert err <= tol and remember the worst err seen under (group, name): dumped to $SPH_TEST_EVIDENCE_DIR/<group>.json at
+    exit.  SPH_TEST_RECORD_ONLY=1 measures without asserting (the recording run the bounds are then set from)."""
+    import os
+    g = _BOUNDS.setdefault(group, {})
+    if name not in g or err > g[name][0]:
+        g[name] = (float(err), float(tol))
+    if os.environ.get("SPH_TEST_RECORD_ONLY") != "1":
+        assert err <= tol, f"{group}: {name}: {err:.3e} > {tol:.1e}"
+    return err
+
+
+def _dump_bounds():
+    import json
+    for group, g in _BOUNDS.items():
+        out = evidence_path(group + ".json")
+        if out is None:
+            continue
+        try:
+            json.dump({k: {"measured": v[0], "bound": v[1]} for k, v in sorted(g.items())}, open(out, "w"), indent=1)
+        except OSError:
+            pass
+
+
+import atexit as _atexit
+_atexit.register(_dump_bounds)

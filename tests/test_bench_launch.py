@@ -183,4 +183,17 @@ def test_bench_refuses_a_world_that_differs_from_gpus():
     env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=120)
-    assert p.returncode != 0 and b"WORLD_SIZE=3" in p.stderr
+    assert p.returncode == 2
+    line = json.loads(p.stdout.decode().strip().splitlines()[-1])      # never die without a line
+    assert line["value"] is None and line["error"] == "invocation" and "WORLD_SIZE=3" in line["detail"]
+
+
+def test_bench_ignores_an_inherited_world_size_without_a_launcher():
+    """WORLD_SIZE alone (no RANK) is an outer environment's leftover, not a launcher: `python bench.py` must not try to join
+    a job of that size -- it goes on as one rank and fails for the real reason here (no GPU), not for the mismatch."""
+    env = dict(os.environ, WORLD_SIZE="4")
+    env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    assert b"WORLD_SIZE=4" not in p.stderr and b"WORLD_SIZE=4" not in p.stdout
+    assert b"needs a GPU" in p.stderr or p.returncode == 0

@@ -184,6 +184,73 @@ def test_local_slabs_restart_from_a_state(which):
 
 
 @pytest.mark.gpu
+def test_restart_with_dynamic_bodies_keeps_the_rest_centre_of_mass(tmp_path):
+    """a restart (`state` = positions / velocities by persistent id) keeps x_0 at the scene file's rest
+    shape -- and must take the bodies' REST centre of mass from x_0 too (the reference computes it while x_0 == x,
+    sph_base.py:80-90, 182-192), not from the displaced restart positions: shape matching pairs x_0 - rest_cm with x - cm
+    (sph_base.py:206-218), so a rest centre taken from x makes every body jump at its first solve_constraints.  Single domain
+    and two slabs: rigid_rest_cm bit-equal to the uninterrupted run's, and the continued trajectory follows it."""
+    import copy
+    from sph_taichi_amd import ParticleSystem, SimConfig
+    from sph_taichi_amd.distributed import SlabSolver, run_local_slabs, gather_by_pid
+    sd = scenes.fluid_with_rigid_bodies(str(tmp_path / "cube.obj"), fluid_velocity=(0.8, -1.0, 0.0))
+    cfg, sc = scenes.build(sd)
+    n = sc.particle_max_num
+    rigid = (sc.arrays["material"] == 0) & (sc.arrays["is_dynamic"] == 1)
+    ps, solver = scenes.make_ps(sd)
+    solver.initialize()
+    rest_cm = ps.rigid_rest_cm.to_numpy().copy()
+    solver.step(30)
+    state = {"x": scenes.ps_by_pid(ps, "x"), "v": scenes.ps_by_pid(ps, "v")}
+    moved = np.abs(state["x"][rigid] - sc.arrays["x"][rigid]).max()
+    assert moved > 0.01, "the bodies have not moved: the restart would not notice a rest centre taken from x"
+    solver.step(12)
+    ref = scenes.ps_by_pid(ps, "x")
+    ps.close()
+    # single domain, restarted
+    ps2 = ParticleSystem(SimConfig(config=copy.deepcopy(sd)), state=state)
+    solver2 = ps2.build_solver()
+    solver2.initialize()
+    got = ps2.rigid_rest_cm.to_numpy()
+    for oid in (1, 2):
+        assert np.array_equal(got[oid], rest_cm[oid]), f"body {oid}: rest centre {got[oid]} != {rest_cm[oid]} of the uninterrupted run"
+    solver2.step(12)
+    x2 = scenes.ps_by_pid(ps2, "x")
+    ps2.close()
+    assert scenes.rel_l2(x2, ref) <= 2e-6 and scenes.rel_l2(x2[rigid], ref[rigid]) <= 2e-6
+    # two slabs, restarted
+    solvers = [SlabSolver(sd, r, 2, device=0, state=state) for r in range(2)]
+    run_local_slabs(solvers, 0, initialize=True)
+    for s in solvers:
+        got = s.ps.rigid_rest_cm.to_numpy()
+        for oid in (1, 2):
+            assert np.array_equal(got[oid], rest_cm[oid])
+    run_local_slabs(solvers, 12)
+    x3 = gather_by_pid(solvers, "x", n)
+    for s in solvers:
+        s.close()
+    assert not np.isnan(x3).any()
+    assert scenes.rel_l2(x3, ref) <= 2e-6 and scenes.rel_l2(x3[rigid], ref[rigid]) <= 2e-6
+
+
+@pytest.mark.gpu
+def test_slab_rank_checkpoint_does_not_trip_over_consumed_accelerations(tmp_path):
+    """after a fused sph_slab_forces the interior accelerations are never materialised and their download is
+    refused; save_state() of that rank's ParticleSystem must still write a checkpoint (the field is dead across steps)."""
+    from sph_taichi_amd.distributed import SlabSolver, run_local_slabs
+    sd = _slab_scenes()[0]
+    solvers = [SlabSolver(sd, r, 2, device=0) for r in range(2)]
+    run_local_slabs(solvers, 0, initialize=True)
+    run_local_slabs(solvers, 3)
+    ck = str(tmp_path / "rank0.npz")
+    solvers[0].ps.save_state(ck)
+    z = np.load(ck)
+    assert z["x"].shape[0] == solvers[0].ps.count() and z["acceleration"].shape == z["x"].shape and np.isfinite(z["acceleration"]).all()
+    for s in solvers:
+        s.close()
+
+
+@pytest.mark.gpu
 def test_interior_accelerations_are_refused_while_they_are_not_materialised():
     """in slab mode the interior force sweep integrates its targets in its finish and does not write their
     accelerations out; a download used to return stale values silently.  Now it fails with a message, and a stand-alone

@@ -2,6 +2,8 @@
 identical inputs.  Integer/index work is bit-exact; f32 fields are compared with
 the tolerances written next to each check (north_star: <= 1e-4 relative L2 on
 positions after N steps)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -10,7 +12,10 @@ import scenes
 pytestmark = pytest.mark.gpu
 
 IMPLS = [(0, 0), (1, 0), (1, 1)]      # (gather_impl, brick partition: 0 = adaptive height, 1 = fixed 4x2x4)
-F_TOL = {"m_V": 2e-5, "density": 2e-5, "pressure": 5e-5, "acceleration": 1e-4, "v": 2e-5, "x": 2e-6}
+# max |err| / max |ref| per field.  Round 6 (VERDICT r05 "weak" #2): <= 3 x the worst value measured over every kernel stage
+# (profiles/r05f_parity_errors.json: m_V 2.3e-7, density 7.9e-7, pressure 2.0e-6, acceleration 9.7e-6 whole-step / 3.6e-6 per
+# kernel, v 2.1e-6, x 3.2e-7); before: 2e-5 / 2e-5 / 5e-5 / 1e-4 / 2e-5 / 2e-6
+F_TOL = {"m_V": 1e-6, "density": 3e-6, "pressure": 1e-5, "acceleration": 3e-5, "v": 1e-5, "x": 1e-6}
 
 
 def _permuted(sc, seed):
@@ -46,7 +51,8 @@ def _cmp(name, got, ref, tol):
     key = name.split(" impl=")[0].split(" (")[0]
     if key not in _MEASURED or err > _MEASURED[key][0]:
         _MEASURED[key] = (err, tol)
-    assert err <= tol, f"{name}: max err / max|ref| = {err:.3e} > {tol:.1e}"
+    if os.environ.get("SPH_TEST_RECORD_ONLY") != "1":     # (a recording run measures without asserting: how the bounds were set)
+        assert err <= tol, f"{name}: max err / max|ref| = {err:.3e} > {tol:.1e}"
     return err
 
 
@@ -154,10 +160,10 @@ def test_edge_cases():
             o.initialize(); solver.initialize()
             assert np.array_equal(ps.pid.to_numpy(), o["pid"])
             o.compute_densities(); solver.compute_densities()
-            _cmp(f"crowded{cnt} density impl={impl},{shape}", ps.density.to_numpy(), o["density"], 5e-5)
+            _cmp(f"crowded{cnt} density impl={impl},{shape}", ps.density.to_numpy(), o["density"], 3e-6)
             o.compute_non_pressure_forces(); solver.compute_non_pressure_forces()
             o.compute_pressure_forces(); solver.compute_pressure_forces()
-            _cmp(f"crowded{cnt} acc impl={impl},{shape}", ps.acceleration.to_numpy(), o["acceleration"], 5e-3)
+            _cmp(f"crowded{cnt} acc impl={impl},{shape}", ps.acceleration.to_numpy(), o["acceleration"], 1e-5)
             ps.close()
 
     sd = scenes.fluid_only(counts=(6, 6, 6), start=(0.04, 0.04, 0.04), velocity=(-3.0, -3.0, -3.0))
@@ -206,12 +212,12 @@ def test_random_clouds_on_awkward_grids(dom, n, seed):
         assert np.array_equal(ps.pid.to_numpy(), o["pid"])
         o.compute_static_boundary_volume(); solver.compute_static_boundary_volume()
         o.compute_moving_boundary_volume(); solver.compute_moving_boundary_volume()
-        _cmp(f"m_V {impl},{shape}", ps.m_V.to_numpy(), o["m_V"], 3e-5)
+        _cmp(f"m_V {impl},{shape}", ps.m_V.to_numpy(), o["m_V"], 1e-6)
         o.compute_densities(); solver.compute_densities()
-        _cmp(f"density {impl},{shape}", ps.density.to_numpy(), o["density"], 3e-5)
+        _cmp(f"density {impl},{shape}", ps.density.to_numpy(), o["density"], 3e-6)
         o.compute_non_pressure_forces(); solver.compute_non_pressure_forces()
         o.compute_pressure_forces(); solver.compute_pressure_forces()
-        _cmp(f"acc {impl},{shape}", ps.acceleration.to_numpy(), o["acceleration"], 2e-4)
+        _cmp(f"acc {impl},{shape}", ps.acceleration.to_numpy(), o["acceleration"], 1e-5)
         ps.close()
         # and the fused device loop from the same state
         o2 = Oracle(params, a, n_objects=1)
@@ -438,7 +444,8 @@ def test_long_run_of_dynamic_bodies_follows_the_oracle():
 # ---------------------------------------------------------------------------
 # DFSPH (simulationMethod 4, DFSPH.py) on the same machinery
 # ---------------------------------------------------------------------------
-DF_TOL = {"density": 2e-5, "dfsph_factor": 5e-5, "density_adv": 3e-5, "acceleration": 2e-4, "v": 3e-5, "x": 2e-6}
+# (measured: dfsph_factor 3.8e-6, density_adv 5.6e-6, acceleration 3.6e-6, v 7.9e-7, x 1.2e-7; before 5e-5 / 3e-5 / 2e-4 / 3e-5 / 2e-6)
+DF_TOL = {"density": 3e-6, "dfsph_factor": 1.2e-5, "density_adv": 2e-5, "acceleration": 3e-5, "v": 3e-6, "x": 1e-6}
 
 
 def _dfsph_scene(moving=True):
@@ -593,7 +600,7 @@ def test_dfsph_crowded_cell_overflow_paths():
                       ("compute_density_change", "compute_density_change", "density_adv"),
                       ("compute_non_pressure_forces", "compute_non_pressure_forces", "acceleration")):
         getattr(o, om)(); getattr(solver, sm)()
-        _cmp(f"crowded {om}", getattr(ps, f).to_numpy(), o[f], 5e-4)
+        _cmp(f"crowded {om}", getattr(ps, f).to_numpy(), o[f], 5e-6)
     ps.close()
 
 
@@ -718,7 +725,7 @@ def test_force_paths_general_and_uniform(uniform):
     o.step(20); solver.step(20)
     assert ps.get_option(_lib.OPT_UNIFORM_FLUID_STATE) == (1 if uniform == -1 else 0)
     assert scenes.rel_l2(scenes.ps_by_pid(ps, "x"), o.by_pid("x")) <= 1e-4
-    _cmp("acceleration", scenes.ps_by_pid(ps, "acceleration"), o.by_pid("acceleration"), 2e-4)
+    _cmp("acceleration", scenes.ps_by_pid(ps, "acceleration"), o.by_pid("acceleration"), 3e-5)
     ps.close()
 
 

@@ -3,9 +3,13 @@ rotate / translate sequence of particle_system.py:421-431, and a restatement of
 `mesh.voxelized(pitch).fill().points` (particle_system.py:441-444; algorithm of
 trimesh.voxel.creation.voxelize_subdivide + binary hole filling).
 
-Voxel-set equality with trimesh itself is not guaranteed (trimesh is absent from
-this image, so it cannot be checked here); scenes that need bit-level ingestion
-parity should ship the point set (`"voxelizedPointsFile": x.npy` in the body).
+Voxel-set equality with trimesh itself cannot be checked here (trimesh is absent from
+this image).  What IS checked (tests/test_voxelizer_crosscheck.py, against the test tree's
+second, differently built implementation of the same published recipe plus a geometric
+inside / outside classifier): identical voxel SETS on the reference's Dragon_50k.obj as every
+scene file places it, on bunny_sparse.obj and on rotated / stretched cubes.  Scenes that need
+bit-level ingestion parity with a trimesh installation should ship the point set
+(`"voxelizedPointsFile": x.npy` in the body).
 """
 from __future__ import annotations
 

@@ -150,6 +150,7 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     c->opt_exact_math = 0;
     c->opt_rigid_x0 = 0;
     c->opt_pure_instance = 1;
+    c->opt_brick_rec = 1;
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
         if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -191,6 +192,7 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     c->brick_cap = ((params->grid_num[0] + 3) / 4) * ((params->grid_num[1] + 1) / 2) * params->grid_num[2] + 8;
     rc = rc ? rc : alloc_dev(c, (void**)&c->brick_list, (size_t)c->brick_cap * 8);
     rc = rc ? rc : alloc_dev(c, (void**)&c->brick_count, 16);
+    rc = rc ? rc : alloc_dev(c, (void**)&c->brick_rec, (size_t)c->brick_cap * 32 * sizeof(int4));   // 512 B per brick slot
     rc = rc ? rc : alloc_dev(c, (void**)&c->brick_list2, (size_t)c->brick_cap * 8);
     rc = rc ? rc : alloc_dev(c, (void**)&c->brick_count2, 16);
     const size_t cold = params->cold_capacity > 0 ? (size_t)params->cold_capacity : cap;
@@ -254,7 +256,7 @@ int32_t sph_destroy(SphContext* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->xm[0], c->xm[1], c->vf[0], c->vf[1], c->aux[0], c->aux[1], c->key[0], c->key[1], c->eos, c->stg, c->gat, c->acc,
                     c->acc_tmp, c->cell_buf[0], c->cell_buf[1], c->rank_off, c->idx_unstable, c->scan_status, c->x0_cold, c->color_cold,
-                    c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->acc_fx, c->rigid_part, c->rigid_R, c->df_err, c->df_part, c->stage, c->glist, c->gcnt, c->brick_list, c->brick_count, c->brick_list2, c->brick_count2};
+                    c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->acc_fx, c->rigid_part, c->rigid_R, c->df_err, c->df_part, c->stage, c->glist, c->gcnt, c->brick_list, c->brick_count, c->brick_list2, c->brick_count2, c->brick_rec};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < SPH_MAX_TIMED_STEPS; ++s)
         for (int k = 0; k < 5; ++k) if (c->ev[s][k]) (void)hipEventDestroy(c->ev[s][k]);
@@ -299,6 +301,7 @@ int32_t sph_set_option(SphContext* c, int32_t option, int32_t value) {
         case SPH_OPT_UNIFORM_FLUID: if (value < -1 || value > 1) return sph_fail(c, SPH_E_INVALID, "uniform-fluid option must be -1, 0 or 1"); c->opt_uniform = value; c->uniform_state = -1; return 0;
         case SPH_OPT_RIGID_SUMS_FROM_X0: c->opt_rigid_x0 = value ? 1 : 0; return 0;
         case SPH_OPT_PURE_FLUID_INSTANCE: c->opt_pure_instance = value ? 1 : 0; sph_invalidate_lists(c); return 0;
+        case SPH_OPT_BRICK_RECORDS: c->opt_brick_rec = value ? 1 : 0; sph_invalidate_lists(c); return 0;
     }
     return sph_fail(c, SPH_E_INVALID, "unknown option");
 }
@@ -324,6 +327,7 @@ int32_t sph_get_option(const SphContext* c, int32_t option, int32_t* value) {
         case SPH_OPT_UNIFORM_FLUID_STATE: *value = c->uniform_state; return 0;
         case SPH_OPT_RIGID_SUMS_FROM_X0: *value = c->opt_rigid_x0; return 0;
         case SPH_OPT_PURE_FLUID_INSTANCE: *value = c->opt_pure_instance; return 0;
+        case SPH_OPT_BRICK_RECORDS: *value = c->opt_brick_rec; return 0;
     }
     return SPH_E_INVALID;
 }

@@ -809,7 +809,8 @@ template <int MODE, class CFG, int VAR = 0>
 __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gather_brick(DevView d, int nby, const int2* __restrict__ brick_list,
                                                       const int* __restrict__ brick_count,
                                                       unsigned short* __restrict__ glist,
-                                                      unsigned char* __restrict__ gcnt, int cap, int list_cap, int lshift) {
+                                                      unsigned char* __restrict__ gcnt, int cap, int list_cap, int lshift,
+                                                      int4* __restrict__ brec, int use_rec) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool HAS_W = !mode_reads_list<MODE>();
     constexpr bool V_GROUPS = (VAR & SPH_VAR_GROUPS) != 0 && !mode_reads_list<MODE>();
@@ -860,15 +861,24 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
     const int chunkh = (nbh + 7) >> 3, chunkl = (nbl + 7) >> 3;
     const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
     int2 brick;
+    int bidx;  // the brick's index in the list (= row of its column record, see step A)
     if (slot < chunkh) {  // heavy bricks first (blocks are dispatched in blockIdx order) ...
         const int kb = xcd * chunkh + slot;
         if (kb >= nbh) return;
-        brick = brick_list[kb];
+        bidx = kb;
     } else {  // ... the light ones fill the tail
         const int kb = xcd * chunkl + (slot - chunkh);
         if (slot - chunkh >= chunkl || kb >= nbl) return;
-        brick = brick_list[list_cap - 1 - kb];
+        bidx = list_cap - 1 - kb;
     }
+    // A list-READING sweep over the partition and the target ranges of the sweep that wrote the lists (use_rec) finds the
+    // outcome of step A -- the four column tables -- in that sweep's per-brick record and needs nothing else of the brick:
+    // one round trip (16 bytes per lane) instead of list entry -> 7 cell_end words per column -> two wave scans.  Positions do
+    // not change between the density sweep and the last sweep that reads its lists (one force sweep in WCSPH, ~18 sweeps in a
+    // DFSPH step), so every reader was recomputing the same tables (VERDICT r05 "next" #8).
+    const bool from_rec = mode_reads_list<MODE>() && use_rec != 0;
+    if (from_rec) brick = make_int2(0, 0);
+    else brick = brick_list[bidx];
     {
     // (column group, first z layer | height << 16): the partition of k_brick_list
     const int byi = brick.x % nby;
@@ -884,6 +894,13 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                 Oz = (float)(sz0 + d.oz) * d.grid_size;
 
     // ---- step A: per shell column, the cell-end table and the segment scan (wave 0) ----
+    if (from_rec) {
+        if (tid < 32) {   // (lanes >= the brick's column count hold the totals, like the tables they stand for)
+            const int4 r = brec[(size_t)bidx * 32 + tid];
+            sColG[tid] = r.x; sColS[tid] = r.y; sTG[tid] = r.z; sTOff[tid] = r.w;
+            if (tid == 31) { sColS[64] = r.y; sTOff[64] = r.w; }
+        }
+    } else
     if (wave == 0) {
         int len = 0, tlen = 0, gstart = 0, tstart = 0;
         if (lane < ncols) {
@@ -909,6 +926,9 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
         sTG[lane] = tstart;
         sTOff[lane] = tincl - tlen;
         if (lane == 63) { sColS[64] = incl; sTOff[64] = tincl; }
+        // the list-writing sweep leaves the tables behind for the readers of its lists (32 x 16 bytes per brick)
+        if (mode_writes_list<MODE>() && brec != nullptr && lane < 32)
+            brec[(size_t)bidx * 32 + lane] = make_int4(gstart - (incl - len), incl - len, tstart, tincl - tlen);
     }
     __syncthreads();
     SPH_TS(1);
@@ -1636,8 +1656,22 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
             c->bricks_valid = true;
         }
     }
+    // the per-brick column records: written by a list-writing sweep over the cached list of the main stream, read back by
+    // the list readers whose target ranges are exactly the writer's (a subset sweep -- slab mode -- has other target tables)
+    int use_rec = 0;
+    int4* brec = nullptr;
+    if (c->brick_rec && blist == c->brick_list && c->opt_brick_rec) {
+        if (mode_writes_list<MODE>()) {
+            brec = c->brick_rec;
+            memcpy(c->brec_key, key, sizeof(key));
+            c->brec_valid = true;     // (stream order: every later sweep runs behind this launch)
+        } else if (mode_reads_list<MODE>() && c->brec_valid && memcmp(key, c->brec_key, sizeof(key)) == 0) {
+            brec = c->brick_rec;
+            use_rec = 1;
+        }
+    }
     hipLaunchKernelGGL((k_gather_brick<MODE, CFG, VAR>), dim3(grid), dim3(TPB), bytes, st, d, nby, blist, bcount, c->glist,
-                       c->gcnt, c->cap, c->brick_cap, c->glist_shift);
+                       c->gcnt, c->cap, c->brick_cap, c->glist_shift, brec, use_rec);
     SPH_LAUNCH_CHECK(c);
     return 0;
 }

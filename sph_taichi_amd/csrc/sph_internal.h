@@ -126,6 +126,11 @@ struct SphContext {
                             // 2^glist_shift bytes, entry r of particle i at (r >> 2) << glist_shift | i * 8 | (r & 3) * 2
     int glist_shift;        // smallest shift with cap * 8 <= 2^shift; 0 = no lists (32-bit offsets would not reach: cell walk)
     unsigned char* gcnt;    // [cap] list lengths (255 = take the global cell walk)
+    int4* brick_rec;        // [brick_cap][32] per-brick column tables (LDS slot -> global, segment start, target start, target offset) left by
+                            // the list-writing sweep for the readers of its lists (k_gather_brick step A); null: not allocated
+    bool brec_valid;        // brick_rec describes the current lists for the partition / target ranges in brec_key
+    int brec_key[5];
+    int opt_brick_rec;      // SPH_OPT_BRICK_RECORDS (default 1)
     int2* brick_list;       // [brick_cap] bricks of the sweep being launched: (column group, first z layer | height << 16)
     int* brick_count;       // device counter
     int brick_cap;
@@ -193,7 +198,7 @@ DevView sph_view(const SphContext* c);
 static inline hipStream_t sph_stream(const SphContext* c) { return c->use_side ? c->side : c->stream; }
 // particle positions / order / flags changed: neighbour lists and the non-empty-brick list are stale
 #define SPH_BRICK_HEAVY 160  // targets from which a brick counts as heavy (a full 4x2x4 brick at rest has 256)
-static inline void sph_invalidate_lists(SphContext* c) { c->lists_valid = false; c->bricks_valid = false; c->stg_kind = 0; c->k_kind = 0; }
+static inline void sph_invalidate_lists(SphContext* c) { c->lists_valid = false; c->bricks_valid = false; c->brec_valid = false; c->stg_kind = 0; c->k_kind = 0; }
 int sph_fail(SphContext* c, int code, const char* what);
 // the particle SET changed (records appended / dropped / re-selected): whatever a device-side check established about it is void
 static inline void sph_forget_pure_fluid(SphContext* c) { c->pure_fluid = 0; c->pure_fluid_n = -1; }

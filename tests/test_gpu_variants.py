@@ -193,3 +193,31 @@ def test_pure_fluid_instance_of_the_density_sweep_is_bit_identical():
         ps.close()
     for n in out[0]:
         assert np.array_equal(out[0][n], out[1][n]), f"{n} differs between the pure-fluid and the general instance"
+
+
+@pytest.mark.parametrize("dfsph", [False, True])
+def test_brick_column_records_change_nothing(dfsph, tmp_path):
+    """SPH_OPT_BRICK_RECORDS (round 6): the list-writing density sweep leaves every brick's column tables in HBM and the list
+    readers (the fused force sweep; every later sweep of a DFSPH step) load them instead of recomputing them from the cell
+    array.  The tables are the same integers, so positions, velocities, densities -- and under DFSPH the solver's iteration
+    counts -- must be BIT-identical with the option off, on a scene with solids, bodies and partly filled bricks."""
+    from sph_taichi_amd import _lib
+    sd = scenes.fluid_with_rigid_bodies(str(tmp_path / "cube.obj"), fluid_velocity=(0.8, -1.0, 0.0))
+    if dfsph:
+        sd = scenes.as_dfsph(sd)
+    cfg, sc = scenes.build(sd)
+    out = []
+    for rec in (1, 0):
+        ps, solver = scenes.make_ps(sd, sc.arrays)
+        assert ps.get_option(_lib.OPT_BRICK_RECORDS) == 1          # the default
+        ps.set_option(_lib.OPT_BRICK_RECORDS, rec)
+        solver.initialize()
+        solver.step(6 if dfsph else 20)
+        got = {n: scenes.ps_by_pid(ps, n) for n in ("x", "v", "density")}
+        if dfsph:
+            st = solver.stats()
+            got["iterations"] = np.array([st["total_iterations_v"], st["total_iterations"]])
+        out.append(got)
+        ps.close()
+    for n in out[0]:
+        assert np.array_equal(out[0][n], out[1][n]), f"{n} differs with the brick records on / off"

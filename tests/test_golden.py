@@ -175,8 +175,11 @@ def test_high_face_fixtures_keep_particles_in_the_last_layers(path):
 # #2): every bound <= 3 x the worst value a recording run measured over all fixtures and both gather implementations
 # (profiles/r06*_golden_errors.json; before: v 5e-5, acceleration 2e-4, m_V / density 2e-5, pressure 1e-4 -- 5-25 x looser
 # than anything measured, so a 5 x regression would have passed).
-HIP_TOL = {"x": 2e-6, "x_0": 0.0, "v": 1e-5, "acceleration": 3e-5, "m_V": 2e-6, "m": 0.0, "density": 3e-6, "pressure": 1e-5}
-HIP_TOL_DFSPH = {"v": 1e-5, "acceleration": 3e-5, "dfsph_factor": 2e-5, "density_adv": 2e-5}
+# Recording run r06a (profiles/r06a_golden_errors_recording_run.json), worst over the 13 fixtures x 2 implementations: x 1.6e-6
+# (high_faces_rigid, step 1: a shape-matched body clamped at two walls), v 5.3e-6, acceleration 4.6e-6, m_V 3.7e-7, density 7.6e-7,
+# pressure 6.0e-6, dfsph_factor 4.2e-7, density_adv 3.4e-6.
+HIP_TOL = {"x": 5e-6, "x_0": 0.0, "v": 1.5e-5, "acceleration": 1.5e-5, "m_V": 1.2e-6, "m": 0.0, "density": 2.5e-6, "pressure": 1.8e-5}
+HIP_TOL_DFSPH = {"v": 1.5e-5, "acceleration": 1.5e-5, "dfsph_factor": 1.5e-6, "density_adv": 1e-5}
 
 
 @pytest.mark.gpu

@@ -9,7 +9,8 @@ import scenes
 pytestmark = pytest.mark.gpu
 
 # one step on the coupled scene, max |err| / max |ref| against the oracle (bounds: <= 3 x the recording run's worst, see scenes.bound)
-ONE_STEP_TOL = (("density", 2e-5), ("pressure", 2e-4), ("acceleration", 5e-4))
+# (recording run r06a, profiles/r06a_variant_errors_recording_run.json: density 2.7e-7, pressure 2.1e-6, acceleration 2.0e-6; before: 2e-5 / 2e-4 / 5e-4)
+ONE_STEP_TOL = (("density", 1e-6), ("pressure", 7e-6), ("acceleration", 7e-6))
 VARIANTS = [0, 1, 8, 16, 24, 25, 57]  # baseline; GROUPS; the force bits; default = GROUPS | BF | DEEP; 57 = default | MFMA (the filter on the matrix pipe)
 
 
@@ -39,7 +40,7 @@ def test_variant_follows_the_oracle(variant):
         scenes.bound("variant_errors", f"oracle one step: {name} (variant {variant})", err, tol)
     o.step(19); solver.step(19)
     err = scenes.rel_l2(scenes.ps_by_pid(ps, "x"), o.by_pid("x"))
-    scenes.bound("variant_errors", f"oracle 20 steps: rel-L2(x) (variant {variant})", err, 1e-4)
+    scenes.bound("variant_errors", f"oracle 20 steps: rel-L2(x) (variant {variant})", err, 2e-7)   # north_star: 1e-4; measured 5.1e-8
     ps.close()
 
 
@@ -56,7 +57,7 @@ def test_variant_on_crowded_cells(variant):
     ps, solver = _system(sd, sc.arrays, variant)
     o.initialize(); solver.initialize()
     o.step(1); solver.step(1)
-    for name, tol in (("density", 5e-5), ("acceleration", 5e-3)):
+    for name, tol in (("density", 4e-6), ("acceleration", 8e-6)):      # measured 1.2e-6 / 2.6e-6 (before: 5e-5 / 5e-3)
         ref, got = o.by_pid(name), scenes.ps_by_pid(ps, name)
         err = float(np.abs(got.astype(np.float64) - ref).max()) / max(float(np.abs(ref).max()), 1e-30)
         scenes.bound("variant_errors", f"crowded: {name} (variant {variant})", err, tol)
@@ -78,7 +79,7 @@ def test_variants_agree_with_each_other_on_a_ragged_lattice():
         if base is None:
             base = got
             continue
-        for n, tol in (("density", 2e-6), ("acceleration", 2e-5), ("x", 1e-7)):
+        for n, tol in (("density", 1e-7), ("acceleration", 2e-6), ("x", 1e-7)):   # measured 0 / 5.5e-7 (the matrix-pipe variant's emission order) / 0
             err = float(np.abs(got[n] - base[n]).max()) / max(float(np.abs(base[n]).max()), 1e-30)
             scenes.bound("variant_errors", f"ragged lattice vs variant 0: {n} (variant {variant})", err, tol)
 
@@ -104,7 +105,7 @@ def test_long_lists_between_64_and_95_entries(variant):
     ps._call("sph_get_stats", st)
     assert 64 < st.max_list <= 95 and st.list_overflow_targets == 0 and st.lds_overflow_targets == 0, \
         (st.max_list, st.list_overflow_targets, st.lds_overflow_targets)
-    for name, tol in (("density", 5e-5), ("acceleration", 2e-3)):
+    for name, tol in (("density", 1.5e-6), ("acceleration", 4e-6)):     # measured 5.0e-7 / 1.2e-6 (before: 5e-5 / 2e-3)
         ref, got = o.by_pid(name), scenes.ps_by_pid(ps, name)
         err = float(np.abs(got.astype(np.float64) - ref).max()) / max(float(np.abs(ref).max()), 1e-30)
         scenes.bound("variant_errors", f"long lists: {name} (variant {variant})", err, tol)
@@ -139,7 +140,7 @@ def test_exact_math_instance_follows_the_oracle_at_least_as_closely():
             with pytest.raises(_lib.SphError, match="profiling build"):
                 ps.set_option(_lib.OPT_DEBUG_ABLATE, 1)
         ps.close()
-    for name, tol in ONE_STEP_TOL + (("x20", 1e-4),):
+    for name, tol in ONE_STEP_TOL + (("x20", 2e-7),):
         for exact in (0, 1):
             scenes.bound("variant_errors", f"exact math {exact}: {name}", errs[exact][name], tol)
     assert errs[1]["density"] <= 2.0 * errs[0]["density"] + 1e-6 and errs[1]["acceleration"] <= 2.0 * errs[0]["acceleration"] + 1e-6, errs

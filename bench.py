@@ -265,6 +265,9 @@ def main():
     ap.add_argument("--brick-shape", type=int, default=0)
     ap.add_argument("--fused", type=int, default=1)
     ap.add_argument("--variant", type=int, default=-1, help="SPH_OPT_KERNEL_VARIANT mask (-1 = the library's default)")
+    ap.add_argument("--brick-records", type=int, default=1, choices=[0, 1],
+                    help="SPH_OPT_BRICK_RECORDS: 1 (default) = the list-reading sweeps load the brick column tables the density sweep left "
+                         "behind, 0 = every sweep recomputes them from the cell array (A/B; bit-identical results)")
     ap.add_argument("--cpu-steps", type=int, default=10, help="CPU-oracle sample size (0 = skip the baseline leg)")
     ap.add_argument("--sweep", action="store_true", help="also time every gather variant (stderr table)")
     ap.add_argument("--time-every", type=int, default=8,
@@ -336,6 +339,7 @@ def main():
     sd = scene_dict(args.workload, args.solver)
     ps = ParticleSystem(SimConfig(config=copy.deepcopy(sd)), device=local_rank)
     solver = ps.build_solver()
+    ps.set_option(_lib.OPT_BRICK_RECORDS, args.brick_records)
     N = ps.particle_max_num
     G = int(ps.grid_num[0] * ps.grid_num[1] * ps.grid_num[2])
 
@@ -421,7 +425,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "solver": "dfsph", "particles": N, "cells": G, "dt": DFSPH_DT,
-                       "gather_impl": args.gather_impl, "parallelism": "1 GPU"},
+                       "gather_impl": args.gather_impl, "brick_records": args.brick_records, "parallelism": "1 GPU"},
             "breakdown_ms": {"sort": round(tm.sort_ms / k, 4), "neighbour": round(tm.neighbour_ms / k, 4),
                              "force": round(tm.force_ms / k, 4), "integrate": round(tm.integrate_ms / k, 4),
                              "sum_of_phases": round(tm.total_ms / k, 4)},
@@ -613,7 +617,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.workload, "particles": N, "cells": G, "dt": CFG["timeStepSize"],
                    "gather_impl": args.gather_impl, "brick_shape": args.brick_shape, "fused": args.fused,
-                   "kernel_variant": ps.get_option(_lib.OPT_KERNEL_VARIANT), "parallelism": "1 GPU",
+                   "kernel_variant": ps.get_option(_lib.OPT_KERNEL_VARIANT), "brick_records": args.brick_records, "parallelism": "1 GPU",
                    "settle_steps": args.settle, "state": "settled" if args.settle else "from rest (steps W..W+K of the initial lattice)"},
         "reps": reps, "timed_seconds": round(t_timed, 3),
         "first_rep": {"value": first["value"], "ms_per_step": first["ms_per_step"]},

@@ -178,6 +178,11 @@ enum SphOption {
                               rows against 16 target columns; a wave's 64 targets are four tiles of 16 consecutive targets, the
                               4-bit row pieces reach their target's lane through a v_permlane32/16_swap transpose (round 5:
                               the A/B the verdict asked for; DESIGN_HISTORY.md).  Same hits, same lists, same sums. */
+#define SPH_VAR_GAT_LDS 2   /* (round 6) uniform-fluid force sweep: the neighbour's SECOND record (v, p / rho^2) is staged in LDS beside the first
+                              instead of gathered through the L1 per pair; tile of 1,408 shell records x 32 B, three workgroups per CU;
+                              the step's bricks are cut for that tile.  Implies FORCE_BF | DEEP.  Same sums (the partition, hence the
+                              list order, differs from the default's where a shell exceeds the smaller tile) */
+#define SPH_VAR_GAT_LDS4 4  /* the same with a tile of 1,200 records: four workgroups per CU, more bricks cut short */
 #define SPH_VAR_FORCE_BF 8 /* force sweep: branch-free fluid pair term, buffer addressing for list and gather */
 #define SPH_VAR_DEEP 16    /* list-reading sweeps: list entries loaded a whole round (3 pairs) before they are decoded */
 /* (r04: bit 64 was SPH_VAR_PERSIST -- both sweeps as PERSISTENT workgroups, grid = the chip's resident slots, bricks taken by

@@ -242,7 +242,7 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     sph_invalidate_lists(c);
     c->opt_uniform = -1; c->uniform_state = -1; c->m_uniform = 0.0f;  // SPH_OPT_UNIFORM_FLUID: auto
     c->opt_variant = SPH_VAR_DEFAULT;
-    if (const char* e = getenv("SPH_KERNEL_VARIANT")) c->opt_variant = atoi(e) & 25;  // A/B aid: the default mask of every context of this process
+    if (const char* e = getenv("SPH_KERNEL_VARIANT")) c->opt_variant = atoi(e) & 31;  // A/B aid: the default mask of every context of this process
     memset(&c->df_stats, 0, sizeof(c->df_stats));
     c->df.enable_divergence_solver = 1; c->df.m_max_iterations_v = 100; c->df.m_max_iterations = 100;  // DFSPH.py:12-20
     c->df.fluid_particle_num = 0; c->df.m_eps = 1e-5f; c->df.reserved_ = 0.0f; c->df.max_error_V = 0.1; c->df.max_error = 0.05;
@@ -294,7 +294,7 @@ int32_t sph_set_option(SphContext* c, int32_t option, int32_t value) {
         case SPH_OPT_EXACT_MATH: c->opt_exact_math = value ? 1 : 0; sph_invalidate_lists(c); return 0;
         case SPH_OPT_DF_RUNAHEAD: c->opt_df_runahead = value ? 1 : 0; return 0;
         case SPH_OPT_KERNEL_VARIANT:
-            if (value < -1 || value > 63 || (value > 0 && (value & 6))) return sph_fail(c, SPH_E_INVALID, "kernel variant must be -1 (default) or a mask of SPH_VAR_*");
+            if (value < -1 || value > 63 || (value > 0 && (value & 6) == 6)) return sph_fail(c, SPH_E_INVALID, "kernel variant must be -1 (default) or a mask of SPH_VAR_* (GAT_LDS and GAT_LDS4 exclude each other)");
             c->opt_variant = value < 0 ? SPH_VAR_DEFAULT : value;
             sph_invalidate_lists(c);
             return 0;

@@ -803,10 +803,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t sph_rsrc(const void* p, unsign
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
 
+template <int MODE, int VAR>
+__host__ __device__ constexpr int brick_waves_per_simd() {
+    if (!mode_reads_list<MODE>()) return 4;
+    if (MODE == GM_FORCE_FUSED_U && (VAR & SPH_VAR_GAT_LDS) != 0) return 3;
+    if (MODE == GM_FORCE_FUSED_U && (VAR & SPH_VAR_GAT_LDS4) != 0) return 4;
+    return 5;
+}
 // second launch bound = waves per SIMD the LDS tile allows anyway (four workgroups per CU for the filtering sweeps, five
 // for the list-reading ones): the register allocator must not go past 128 / 96 VGPRs, or a resident slot is lost
 template <int MODE, class CFG, int VAR = 0>
-__global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gather_brick(DevView d, int nby, const int2* __restrict__ brick_list,
+__global__ __launch_bounds__(TPB, (brick_waves_per_simd<MODE, VAR>())) void k_gather_brick(DevView d, int nby, const int2* __restrict__ brick_list,
                                                       const int* __restrict__ brick_count,
                                                       unsigned short* __restrict__ glist,
                                                       unsigned char* __restrict__ gcnt, int cap, int list_cap, int lshift,
@@ -822,10 +829,16 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
     constexpr bool V_PURE = (VAR & SPH_VAR_PURE_INTERNAL) != 0 && MODE == GM_DENSITY_EOS;
     constexpr bool V_BF = (VAR & SPH_VAR_FORCE_BF) != 0 && MODE == GM_FORCE_FUSED_U;
     constexpr bool V_DEEP = (VAR & SPH_VAR_DEEP) != 0 && mode_reads_list<MODE>();
+    // SPH_VAR_GAT_LDS / _LDS4 (round 6, VERDICT r05 "next" #5): the neighbour's second record (gat: v, p / rho^2) staged in LDS beside
+    // the first instead of gathered through the L1 -- the counters say the force sweep's vector-memory path is busy with TAG
+    // LOOK-UPS, not misses: a wave's 16-byte gather touches ~33 cache lines (profiles/r06b_pmc_ta_*: 51 M L1 accesses for 1.57 M
+    // load instructions, 87 % of them hits, address unit stalled by the cache 27-40 % of the kernel)
+    constexpr bool V_GLDS = (VAR & (SPH_VAR_GAT_LDS | SPH_VAR_GAT_LDS4)) != 0 && MODE == GM_FORCE_FUSED_U;
     constexpr bool V_EXACT = (VAR & SPH_VAR_EXACT) != 0 && (MODE == GM_DENSITY_EOS || MODE == GM_FORCE_FUSED_U);  // SPH_OPT_EXACT_MATH
     constexpr bool INLINE_PHYS = mode_inline_physics<MODE>();  // pair terms inside the emission loop
     float4* sQ = reinterpret_cast<float4*>(smem + CFG::OFF_Q);
     float* sW = reinterpret_cast<float*>(smem + CFG::off_w(HAS_W));  // only when HAS_W
+    float4* sG = reinterpret_cast<float4*>(smem + CFG::bytes(HAS_W));  // only when V_GLDS: the gat records of the shell, behind everything else
     // Shell origin.  Candidates are staged in shell-local coordinates as (-2x', -2y', -2z', |x'|^2) so the
     // filter is |x_i - x_j|^2 - |x_i'|^2 = s_j + x_i'.(-2 x_j') : 3 FMA + 1 compare per candidate.  Local
     // coordinates are <= 6 cells, so the cancellation error (~1e-8) is far below the 2e-4 h^2 filter margin,
@@ -972,6 +985,8 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
     // ---- step B: stage the shell's (x, y, z, m_V) records; all loads of a lane in flight together ----
     if (!overflow) {
         float4 buf[CFG::PER];
+        float4 bufg[V_GLDS ? CFG::PER : 1];
+        (void)bufg;
 #pragma unroll
         for (int u = 0; u < CFG::PER; ++u) {
             const int idx = min(tid + u * TPB, total - 1);  // clamped: the load is always valid
@@ -980,6 +995,7 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
             for (int step = 16; step > 0; step >>= 1)
                 if (sColS[col + step] <= idx) col += step;
             buf[u] = ((MODE == GM_FORCE_FUSED_U || mode_is_df_iter_u<MODE>()) ? d.stg : d.xm)[sColG[col] + idx];
+            if (V_GLDS) bufg[u] = d.gat[sColG[col] + idx];
         }
         // SPH_VAR_GROUPS: the nine candidate runs of every target cell, once per brick instead of once per target (all
         // targets of a cell walk the same runs), computed while the staging loads are in flight: entry (cell, r) =
@@ -1012,6 +1028,7 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                     if (!V_PURE) sW[idx] = buf[u].w;
                 } else {
                     sQ[idx] = buf[u];  // list-reading sweeps: the record as it is, so x_i - x_j is the reference's own f32 difference
+                    if (V_GLDS) sG[idx] = bufg[u];
                 }
             }
         }
@@ -1392,6 +1409,9 @@ __global__ __launch_bounds__(TPB, (mode_reads_list<MODE>() ? 5 : 4)) void k_gath
                     s_.B = make_float4(0.f, 0.f, 0.f, 1.0f);
                 } else
 #endif
+                if (V_GLDS) {
+                    s_.B = sG[s_.j];
+                } else
                 if (V_BF) {
                     typedef float v4f __attribute__((ext_vector_type(4)));
                     const v4f b = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(grs, s_.g << 4, 0, 0));
@@ -1550,8 +1570,16 @@ __global__ __launch_bounds__(TPB) void k_eos(DevView d) {
 // host-side launchers
 // ---------------------------------------------------------------------------
 typedef BrickCfg<4, 2, 4, 1792, 95> Cfg0;  // 4x2 columns x up to 4 layers: 1152 candidates / 256 targets at rest
+// SPH_VAR_GAT_LDS / _LDS4: the force sweep's tile holds two records per shell particle (32 B): smaller tiles, so that three / four
+// workgroups still fit a CU's 160 KiB (45 + 2.3 KiB / 37.5 + 2.3 KiB); the partition of the whole step is cut for them
+typedef BrickCfg<4, 2, 4, 1408, 95> CfgG3;
+typedef BrickCfg<4, 2, 4, 1200, 95> CfgG4;
 // shell records a brick may hold (the cut rule of k_brick_list): the smallest tile among the kernels of the step
-static int brick_smax(const SphContext*) { return Cfg0::CAP; }
+static int brick_smax(const SphContext* c) {
+    if (c->opt_variant & SPH_VAR_GAT_LDS) return CfgG3::CAP;
+    if (c->opt_variant & SPH_VAR_GAT_LDS4) return CfgG4::CAP;
+    return Cfg0::CAP;
+}
 
 template <int MODE>
 static int launch_simple(SphContext* c, const int* list, int n) {
@@ -1614,7 +1642,8 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
     const int ncg = nbx * nby;          // column groups
     const int nbricks = ncg * d.nz;     // at worst every z layer is a brick of its own
     if (nbricks > c->brick_cap) return sph_fail(c, SPH_E_INVALID, "brick list capacity exceeded");
-    const int bytes = CFG::bytes(!mode_reads_list<MODE>());
+    const int bytes = CFG::bytes(!mode_reads_list<MODE>()) +
+                      (((VAR & (SPH_VAR_GAT_LDS | SPH_VAR_GAT_LDS4)) && MODE == GM_FORCE_FUSED_U) ? CFG::CAP * 16 : 0);
     static bool attr_set[64] = {};  // per device: the attribute belongs to the function ON a device
     const int dev = c->device >= 0 && c->device < 64 ? c->device : 0;
     if (!attr_set[dev]) {
@@ -1690,6 +1719,8 @@ static int launch_brick(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, in
     }
     if constexpr (MODE == GM_FORCE_FUSED_U) {
         if (c->opt_exact_math) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_EXACT>(c, lo, hi, lo2, hi2);
+        if (var & SPH_VAR_GAT_LDS) return launch_brick_cfg<MODE, CfgG3, SPH_VAR_FORCE_BF | SPH_VAR_DEEP | SPH_VAR_GAT_LDS>(c, lo, hi, lo2, hi2);
+        if (var & SPH_VAR_GAT_LDS4) return launch_brick_cfg<MODE, CfgG4, SPH_VAR_FORCE_BF | SPH_VAR_DEEP | SPH_VAR_GAT_LDS4>(c, lo, hi, lo2, hi2);
         switch (var & (SPH_VAR_FORCE_BF | SPH_VAR_DEEP)) {
             case SPH_VAR_FORCE_BF: return launch_brick_cfg<MODE, Cfg0, SPH_VAR_FORCE_BF>(c, lo, hi, lo2, hi2);
             case SPH_VAR_DEEP: return launch_brick_cfg<MODE, Cfg0, SPH_VAR_DEEP>(c, lo, hi, lo2, hi2);

@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 # one step on the coupled scene, max |err| / max |ref| against the oracle (bounds: <= 3 x the recording run's worst, see scenes.bound)
 # (recording run r06a, profiles/r06a_variant_errors_recording_run.json: density 2.7e-7, pressure 2.1e-6, acceleration 2.0e-6; before: 2e-5 / 2e-4 / 5e-4)
 ONE_STEP_TOL = (("density", 1e-6), ("pressure", 7e-6), ("acceleration", 7e-6))
-VARIANTS = [0, 1, 8, 16, 24, 25, 57]  # baseline; GROUPS; the force bits; default = GROUPS | BF | DEEP; 57 = default | MFMA (the filter on the matrix pipe)
+VARIANTS = [0, 1, 8, 16, 24, 25, 57, 27, 29]  # baseline; GROUPS; the force bits; default = GROUPS | BF | DEEP; 57 = default | MFMA (the filter on the
+# matrix pipe); 27 / 29 = default | GAT_LDS / GAT_LDS4 (round 6: the force sweep's second neighbour record staged in LDS, smaller tiles)
 
 
 def _system(sd, arrays, variant):
@@ -20,7 +21,7 @@ def _system(sd, arrays, variant):
     ps.set_option(_lib.OPT_KERNEL_VARIANT, variant)
     assert ps.get_option(_lib.OPT_KERNEL_VARIANT) == variant
     ps.set_option(_lib.OPT_KERNEL_VARIANT, -1)            # -1 = the library's default mask
-    assert ps.get_option(_lib.OPT_KERNEL_VARIANT) == _lib.VAR_DEFAULT == 25
+    assert ps.get_option(_lib.OPT_KERNEL_VARIANT) == _lib.VAR_DEFAULT
     ps.set_option(_lib.OPT_KERNEL_VARIANT, variant)
     return ps, solver
 
@@ -44,7 +45,7 @@ def test_variant_follows_the_oracle(variant):
     ps.close()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 24, 25, 57])
+@pytest.mark.parametrize("variant", [0, 1, 24, 25, 57, 27, 29])
 def test_variant_on_crowded_cells(variant):
     """12^3 particles in a (1.5 h)^3 box: > 95 neighbours each, so every list overflows (the force sweep must
     fall back to the exact walk; the range-checked list stores must drop rows >= LISTCAP and nothing else)."""
@@ -84,7 +85,7 @@ def test_variants_agree_with_each_other_on_a_ragged_lattice():
             scenes.bound("variant_errors", f"ragged lattice vs variant 0: {n} (variant {variant})", err, tol)
 
 
-@pytest.mark.parametrize("variant", [0, 24, 25, 57])
+@pytest.mark.parametrize("variant", [0, 24, 25, 57, 27, 29])
 def test_long_lists_between_64_and_95_entries(variant):
     """A slab compressed to ~2.5 x rest density (spacing 0.74 d): 65..95 list entries per interior particle -- beyond
     the 63 of round 1, inside LISTCAP = 95 -- so the list rows >= 64 are written by the density sweep and read back

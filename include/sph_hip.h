@@ -162,7 +162,9 @@ enum SphOption {
     SPH_OPT_PURE_FLUID_INSTANCE = 15 /* 1 (default) = a single context found (on the device) to hold no solid particle at all runs the
                                   density sweep's pure-fluid instance (m_V_j = m_V0 from a register; bit-identical results);
                                   0 = always the general instance (the A/B switch; was the SPH_DISABLE_PURE_FLUID environment
-                                  variable in ABI 4) */,
+                                  variable in ABI 4); 2 = the CALLER vouches that the whole scene holds no solid particle at all
+                                  (slab ranks: arrivals are never checked on the device; the Python layer sets it when the scene
+                                  file has no rigid block and no rigid body) */,
     SPH_OPT_BRICK_RECORDS = 16 /* 1 (default) = the list-WRITING brick sweep (density) leaves each brick's column tables (what step A of
                                   the sweep computes from the cell array: 512 bytes per brick) in HBM, and the list-READING sweeps
                                   over the same partition and target ranges (the fused force sweep; the ~18 sweeps of a DFSPH step)

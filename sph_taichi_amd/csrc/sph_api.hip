@@ -1,6 +1,7 @@
 // sph_api.hip -- the extern "C" surface declared in include/sph_hip.h: context
 // lifetime, field upload/download, one entry point per reference kernel, and
 // sph_step = SPHBase.step() (sph_base.py:263-271) looped on the device.
+#include <sched.h>
 #include "sph_internal.h"
 
 #define SCAN_TILE 2048
@@ -70,7 +71,6 @@ __global__ void k_read_layer_offsets(const int* __restrict__ cell_end, const int
     out[k] = L > 0 ? cell_end[(size_t)L * per_layer - 1] : 0;
 }
 
-struct CellIdx16 { int v[16]; };
 __global__ void k_read_cells(const int* __restrict__ cell_end, CellIdx16 ix, int* __restrict__ out) {
     const int k = threadIdx.x;
     if (k < 16 && ix.v[k] >= 0) out[k] = cell_end[ix.v[k]];
@@ -300,7 +300,9 @@ int32_t sph_set_option(SphContext* c, int32_t option, int32_t value) {
             return 0;
         case SPH_OPT_UNIFORM_FLUID: if (value < -1 || value > 1) return sph_fail(c, SPH_E_INVALID, "uniform-fluid option must be -1, 0 or 1"); c->opt_uniform = value; c->uniform_state = -1; return 0;
         case SPH_OPT_RIGID_SUMS_FROM_X0: c->opt_rigid_x0 = value ? 1 : 0; return 0;
-        case SPH_OPT_PURE_FLUID_INSTANCE: c->opt_pure_instance = value ? 1 : 0; sph_invalidate_lists(c); return 0;
+        case SPH_OPT_PURE_FLUID_INSTANCE:
+            if (value < 0 || value > 2) return sph_fail(c, SPH_E_INVALID, "pure-fluid instance option must be 0, 1 or 2");
+            c->opt_pure_instance = value; sph_invalidate_lists(c); return 0;
         case SPH_OPT_BRICK_RECORDS: c->opt_brick_rec = value ? 1 : 0; sph_invalidate_lists(c); return 0;
     }
     return sph_fail(c, SPH_E_INVALID, "unknown option");
@@ -768,20 +770,28 @@ int32_t sph_layer_offsets(SphContext* c, const int32_t* layers, int32_t n, int32
     return 0;
 }
 
-int32_t sph_layer_offsets_begin(SphContext* c, const int32_t* layers, int32_t n) {
-    ENTER(c);
-    if (!layers || n < 0 || n > 16) return SPH_E_INVALID;
-    if (!c->have_prefix) return sph_fail(c, SPH_E_STATE, "sph_layer_offsets_begin needs the prefix sum");
+// which cells hold the record counts below the given x layers (sets off_zero_mask)
+static int layer_offset_cells(SphContext* c, const int32_t* layers, int32_t n, CellIdx16* ix) {
     const int per_layer = c->p.grid_num[1] * c->p.grid_num[2];
     c->off_zero_mask = 0;
-    CellIdx16 ix;
-    for (int k = 0; k < 16; ++k) ix.v[k] = -1;
+    for (int k = 0; k < 16; ++k) ix->v[k] = -1;
     for (int k = 0; k < n; ++k) {
         const int L = layers[k];
         if (L < 0 || L > c->p.grid_num[0]) return sph_fail(c, SPH_E_INVALID, "layer out of range");
         if (L == 0) { c->off_zero_mask |= 1 << k; continue; }
-        ix.v[k] = L * per_layer - 1;
+        ix->v[k] = L * per_layer - 1;
     }
+    return 0;
+}
+
+int32_t sph_layer_offsets_begin(SphContext* c, const int32_t* layers, int32_t n) {
+    ENTER(c);
+    c->off_stamp_pending = false;   // (this path delivers through k_read_cells + ev_off)
+    if (!layers || n < 0 || n > 16) return SPH_E_INVALID;
+    if (!c->have_prefix) return sph_fail(c, SPH_E_STATE, "sph_layer_offsets_begin needs the prefix sum");
+    CellIdx16 ix;
+    int rc0 = layer_offset_cells(c, layers, n, &ix);
+    if (rc0) return rc0;
     // one tiny kernel writes all offsets straight into mapped pinned memory (n separate device-to-host copies
     // used to sit on the stream between the sort and the density sweep)
     int* dev_out = nullptr;
@@ -795,7 +805,24 @@ int32_t sph_layer_offsets_begin(SphContext* c, const int32_t* layers, int32_t n)
 int32_t sph_layer_offsets_end(SphContext* c, int32_t* out, int32_t n) {
     ENTER(c);
     if (!out || n < 0 || n > 16) return SPH_E_INVALID;
-    SPH_HIP(c, hipEventSynchronize(c->ev_off));
+    if (c->off_stamp_pending) {
+        // the offsets came with the sort (sph_slab_advance): spin on the stamp its place kernel writes behind them.  Bounded:
+        // if the stream has run dry without the stamp (a failed launch), say so instead of spinning for ever.
+        c->off_stamp_pending = false;
+        volatile int* hp = c->h_pinned;
+        long spins = 0;
+        while (__atomic_load_n(&hp[17], __ATOMIC_ACQUIRE) != c->off_stamp) {
+            ++spins;
+            // (several ranks may share the host's cores -- the one-GPU tests run 2-3 of them: past the first few microseconds a
+            // waiting rank gives its core away instead of burning it)
+            if (spins > 4096) sched_yield();
+            if ((spins & 0xffff) == 0 && hipStreamQuery(c->stream) == hipSuccess &&
+                __atomic_load_n(&hp[17], __ATOMIC_ACQUIRE) != c->off_stamp)
+                return sph_fail(c, SPH_E_STATE, "sph_layer_offsets_end: the sort finished without delivering the layer offsets");
+        }
+    } else {
+        SPH_HIP(c, hipEventSynchronize(c->ev_off));
+    }
     for (int k = 0; k < n; ++k) out[k] = (c->off_zero_mask >> k) & 1 ? 0 : c->h_pinned[k];
     return 0;
 }
@@ -913,8 +940,14 @@ int32_t sph_slab_advance(SphContext* c, int32_t keep_first, int32_t keep_count, 
     rc = rc ? rc : sph_select_range(c, keep_first, keep_count);
     rc = rc ? rc : sph_append_records(c, srcL, nL);
     rc = rc ? rc : sph_append_records(c, srcR, nR);
+    // the layer offsets ride in the sort: its place kernel -- the first kernel behind the scan -- copies the scanned cells into
+    // the mapped buffer and ev_off is recorded right behind it (r06: k_read_cells was a launch of its own between the
+    // scatter and the density sweep, 4 us on the stream of every slab step; the host now also gets them a scatter earlier)
+    if (!rc && (!layers || n_layers < 0 || n_layers > 16)) rc = SPH_E_INVALID;
+    if (!rc) rc = layer_offset_cells(c, layers, n_layers, &c->off_ix);
+    if (!rc) c->off_in_sort = true;
     rc = rc ? rc : sort_no_fold(c);
-    rc = rc ? rc : sph_layer_offsets_begin(c, layers, n_layers);
+    c->off_in_sort = false;
     if (!rc && ev) SPH_HIP(c, hipEventRecord(ev[1], c->stream));
     if (!rc && do_sweeps == 1) rc = sph_sweeps(c);
     if (!rc && do_sweeps == 2) {  // boundary volume + density only; sph_slab_forces does the rest

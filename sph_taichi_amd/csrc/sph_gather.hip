@@ -1713,7 +1713,10 @@ static int launch_brick(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0, in
         if (c->opt_exact_math) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS | SPH_VAR_EXACT>(c, lo, hi, lo2, hi2);
         if ((var & SPH_VAR_GROUPS) && (var & SPH_VAR_MFMA)) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS | SPH_VAR_MFMA>(c, lo, hi, lo2, hi2);
         // (pure_fluid is only ever set by a device-side check of THIS particle set: same count, single context)
-        if ((var & SPH_VAR_GROUPS) && c->opt_pure_instance && c->uniform_state == 1 && c->pure_fluid && c->pure_fluid_n == c->N && !c->opt_drop_outside)
+        // ... or the HOST vouches that the whole scene holds no solid particle (SPH_OPT_PURE_FLUID_INSTANCE 2: a slab rank, whose
+        // arrivals are never checked; every particle of such a scene keeps m_V = m_V0 bit for bit wherever it lives)
+        const bool pure_checked = c->opt_pure_instance == 1 && c->pure_fluid && c->pure_fluid_n == c->N && !c->opt_drop_outside;
+        if ((var & SPH_VAR_GROUPS) && c->uniform_state == 1 && (pure_checked || c->opt_pure_instance == 2))
             return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS | SPH_VAR_PURE_INTERNAL>(c, lo, hi, lo2, hi2);
         if (var & SPH_VAR_GROUPS) return launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS>(c, lo, hi, lo2, hi2);
     }
@@ -1768,7 +1771,15 @@ static int launch_df(SphContext* c) {
     }
     // (the group-sorted emission and the early entry loads of SPH_VAR_DEEP do nothing measurable for these sweeps: DFSPH
     // step 3.46 vs 3.51 ms with DEEP, profiles/archive/r02g -- their pair terms gather 4 bytes, not a 16-byte record)
-    int rc = launch_brick_cfg<MODE, Cfg0>(c);
+    // (round 6) ... but the list-WRITING sweep of the step is the same filter + emission as the WCSPH density sweep, and the
+    // group-sorted emission is worth as much to it: 0.333 -> 0.24 ms on the settled 1.75 M box (tools/list_reuse_probe.py had
+    // timed it at the baseline emission's 0.333 against the WCSPH sweep's 0.245)
+    int rc;
+    if constexpr (MODE == GM_DF_DENSITY) {
+        rc = (c->opt_variant & SPH_VAR_GROUPS) ? launch_brick_cfg<MODE, Cfg0, SPH_VAR_GROUPS>(c) : launch_brick_cfg<MODE, Cfg0>(c);
+    } else {
+        rc = launch_brick_cfg<MODE, Cfg0>(c);
+    }
     if (!rc && mode_writes_list<MODE>()) { c->lists_valid = true; c->gcnt_written = true; c->stg_kind = 2; c->k_kind = 0; }
     if (!rc && MODE == GM_DF_DENSITY_CHANGE) c->k_kind = 1;
     if (!rc && MODE == GM_DF_DENSITY_ADV) c->k_kind = 2;

@@ -79,6 +79,8 @@ struct DevView {
     float* rigid_rest_cm;
 };
 
+struct CellIdx16 { int v[16]; };   // up to 16 cell indices whose scanned values the host wants back (slab layer offsets); -1 = unused
+
 struct SphContext {
     SphParams p;
     int device;
@@ -98,6 +100,10 @@ struct SphContext {
     int2* brick_list2;   // [brick_cap] brick list of launches on the side stream
     int* brick_count2;
     int off_zero_mask;   // which of the pending offsets are layer 0 (no copy needed)
+    int off_stamp;       // stamp of the last sort that delivered layer offsets (h_pinned[17] shows it once they are there)
+    bool off_stamp_pending;  // sph_layer_offsets_end waits for the stamp (spinning on mapped memory), not for ev_off
+    bool off_in_sort;    // sph_slab_advance: the sort that follows delivers the layer offsets itself (k_unstable_place reads the
+    CellIdx16 off_ix;    //   scanned cells into the mapped buffer and ev_off is recorded right behind it) -- no launch of their own
     int tgt_layers[4];  // density lo/hi, force lo/hi (slab mode); default 0..nx
     int nx_alloc;       // grid_num[0] at sph_create: what the cell arrays and brick lists are sized for (sph_slab_set_window)
     int in_off;  // first live record of the current set (non-zero only between sph_select_range and the next sort)

@@ -124,9 +124,22 @@ __global__ __launch_bounds__(TPB) void k_scan_fused(int4* __restrict__ data, uns
 }
 
 __global__ __launch_bounds__(TPB) void k_unstable_place(DevView d, const int* __restrict__ rank_off,
-                                                        int* __restrict__ idx_unstable, int* __restrict__ dyn_count) {
+                                                        int* __restrict__ idx_unstable, int* __restrict__ dyn_count,
+                                                        CellIdx16 off_ix, int* __restrict__ off_out, int off_stamp) {
     const int i = blockIdx.x * TPB + threadIdx.x;
     if (i == 0) *dyn_count = 0;  // counted by the scatter that follows (saves a memset launch)
+    // slab ranks: the record counts below a few x layers (scanned cells) go straight into mapped host memory for the driver,
+    // followed -- behind a system-scope fence -- by the sort's stamp: the host spins on the stamp instead of waiting for an event
+    // (an event record is a packet of its own on the stream: 4 us between this kernel and the scatter, r06d trace)
+    if (off_out != nullptr && i == 0) {
+        int v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = off_ix.v[k] >= 0 ? d.cell_end[off_ix.v[k]] : 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) __hip_atomic_store(&off_out[k], v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __atomic_thread_fence(__ATOMIC_RELEASE);   // system scope by default in HIP: the values are visible before the stamp
+        __hip_atomic_store(&off_out[17], off_stamp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (i >= d.N) return;
     const int c = d.key[i];
     const int b = c > 0 ? d.cell_end[c - 1] : 0;  // particle_system.py:327-329 base_offset
@@ -248,7 +261,19 @@ int sphk_sort_scatter(SphContext* c, bool sort_acc) {
     if (bl.nblocks > 0 && !c->brick_count_zero) {  // (a sort without its own hash pass: sph_counting_sort called twice)
         SPH_HIP(c, hipMemsetAsync(c->brick_count, 0, 2 * sizeof(int), c->stream));
     }
-    hipLaunchKernelGGL(k_unstable_place, dim3(nb), dim3(TPB), 0, c->stream, d, c->rank_off, c->idx_unstable, c->dyn_count);
+    CellIdx16 off_ix;
+    int* off_out = nullptr;
+    for (int k = 0; k < 16; ++k) off_ix.v[k] = -1;
+    if (c->off_in_sort) {
+        off_ix = c->off_ix;
+        SPH_HIP(c, hipHostGetDevicePointer((void**)&off_out, c->h_pinned, 0));
+    }
+    if (c->off_in_sort) {
+        c->off_stamp = c->off_stamp == 0x7fffffff ? 1 : c->off_stamp + 1;
+        c->off_stamp_pending = true;
+    }
+    hipLaunchKernelGGL(k_unstable_place, dim3(nb), dim3(TPB), 0, c->stream, d, c->rank_off, c->idx_unstable, c->dyn_count, off_ix, off_out,
+                       c->off_stamp);
     SPH_LAUNCH_CHECK(c);
     if (sort_acc)
         hipLaunchKernelGGL(k_stable_scatter<true>, dim3(nb + bl.nblocks), dim3(TPB), bl.lds_bytes, c->stream, d, c->idx_unstable, c->xm[o],

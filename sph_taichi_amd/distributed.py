@@ -505,6 +505,10 @@ class SlabSolver:
         # mass); then the device checks the local particles once and later arrivals are vouched for
         same_mass = len({float(b["density"]) for b in cfg.get_fluid_blocks()}) <= 1
         self.ps.set_option(_lib.OPT_UNIFORM_FLUID, 1 if same_mass else 0)
+        # ... and whether the scene has any solid at all: without one every m_V stays m_V0 on every rank, and the density sweep
+        # may run its pure-fluid instance (bit-identical; a rank cannot check its arrivals, the scene file can vouch for them)
+        if same_mass and self.ps._scene.solid_particle_num == 0:
+            self.ps.set_option(_lib.OPT_PURE_FLUID_INSTANCE, 2)
         nxl = self._set_target_layers()
         self.solver = self.ps.build_solver()
         self.dfsph = cfg.get_cfg("simulationMethod") == 4

@@ -166,7 +166,16 @@ def profiling_variant() -> bool:
     return os.environ.get("SPH_HIP_LIB_VARIANT", "") == "profile"
 
 
+def experiment_variant() -> str:
+    """SPH_HIP_LIB_VARIANT=x-<tag>: load libsph_hip_x-<tag>.so -- the SAME sources built with other compiler flags by
+    tools/sched_sweep.py (an A/B aid of the measurement tools, never set by the product; the file must exist, it is never built here)."""
+    v = os.environ.get("SPH_HIP_LIB_VARIANT", "")
+    return v if v.startswith("x-") else ""
+
+
 def library_path() -> str:
+    if experiment_variant():
+        return os.path.join(os.path.dirname(_build.LIB), f"libsph_hip_{experiment_variant()}.so")
     return _build.LIB_PROFILE if profiling_variant() else _build.LIB
 
 
@@ -196,7 +205,7 @@ def load(build_if_missing: bool = True):
     if _LIB is not None:
         return _LIB
     path = library_path()
-    if build_if_missing and _build.stale(profiling_variant()):
+    if build_if_missing and not experiment_variant() and _build.stale(profiling_variant()):
         try:
             _build.build(profile=profiling_variant())
         except Exception as e:  # no hipcc on this box: use the prebuilt file if any

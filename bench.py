@@ -268,6 +268,9 @@ def main():
     ap.add_argument("--brick-records", type=int, default=1, choices=[0, 1],
                     help="SPH_OPT_BRICK_RECORDS: 1 (default) = the list-reading sweeps load the brick column tables the density sweep left "
                          "behind, 0 = every sweep recomputes them from the cell array (A/B; bit-identical results)")
+    ap.add_argument("--df-fuse-error", type=int, default=1, choices=[0, 1],
+                    help="SPH_OPT_DF_FUSE_ERROR (--solver dfsph): 1 (default) = the refresh sweep of a solver iteration reduces the density error "
+                         "itself, 0 = a streaming kernel re-reads the particles (A/B)")
     ap.add_argument("--cpu-steps", type=int, default=10, help="CPU-oracle sample size (0 = skip the baseline leg)")
     ap.add_argument("--sweep", action="store_true", help="also time every gather variant (stderr table)")
     ap.add_argument("--time-every", type=int, default=8,
@@ -340,6 +343,7 @@ def main():
     ps = ParticleSystem(SimConfig(config=copy.deepcopy(sd)), device=local_rank)
     solver = ps.build_solver()
     ps.set_option(_lib.OPT_BRICK_RECORDS, args.brick_records)
+    ps.set_option(_lib.OPT_DF_FUSE_ERROR, args.df_fuse_error)
     N = ps.particle_max_num
     G = int(ps.grid_num[0] * ps.grid_num[1] * ps.grid_num[2])
 

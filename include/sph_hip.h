@@ -169,7 +169,12 @@ enum SphOption {
                                   the sweep computes from the cell array: 512 bytes per brick) in HBM, and the list-READING sweeps
                                   over the same partition and target ranges (the fused force sweep; the ~18 sweeps of a DFSPH step)
                                   load them with one 16-byte read per lane instead of recomputing them; 0 = every sweep recomputes
-                                  (A/B).  Same tables, same results bit for bit. */
+                                  (A/B).  Same tables, same results bit for bit. */,
+    SPH_OPT_DF_FUSE_ERROR = 17 /* 1 (default) = inside the DFSPH solver loops (sph_dfsph_divergence_solve / _pressure_solve) the density-change
+                                  / density-advection sweep of an iteration also reduces compute_density_error()'s sum (DFSPH.py:224-230)
+                                  over its own targets -- one f64 partial per brick, added up in brick-list order by the convergence
+                                  test -- instead of a streaming kernel that re-reads every particle; 0 = that kernel (A/B).  The same
+                                  per-particle f32 terms either way; the f64 grouping differs (both deterministic). */
 };
 #define SPH_VAR_GROUPS 1   /* density: all nine runs filtered first (masks in registers), hits emitted centre run / edge runs / corner
                               runs, each group by descending hit count */

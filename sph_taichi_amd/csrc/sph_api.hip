@@ -54,6 +54,7 @@ DevView sph_view(const SphContext* c) {
     d.m_u = c->m_uniform; d.write_sg = 0; d.write_k = 0;
     d.whx = p.wall_hi[0]; d.why = p.wall_hi[1]; d.whz = p.wall_hi[2];
     d.fuse_advect = c->fuse_advect;
+    d.df_bpart = c->df_collect ? c->df_bpart : nullptr;
     d.gate = (c->df_epoch && c->opt_df_runahead) ? c->df_gate : nullptr;   // (without run-ahead no body is ever enqueued past convergence)
     d.gate_epoch = c->df_epoch;
     d.fx_scale = ldexp(1.0, c->rigid_fx_exp);
@@ -146,6 +147,9 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     c->timing_phase = 0;
     c->opt_brick_shape = 0;
     c->opt_rigid_batch = 1;
+    c->opt_df_fuse_err = 1;
+    c->df_collect = 0;
+    c->df_bpart_valid = false;
     c->opt_df_runahead = 0;   // measured (r05): running ahead costs 2 % more than the bubbles it removes
     c->opt_exact_math = 0;
     c->opt_rigid_x0 = 0;
@@ -208,6 +212,7 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     rc = rc ? rc : alloc_dev(c, (void**)&c->rigid_R, 16 * sizeof(float));
     rc = rc ? rc : alloc_dev(c, (void**)&c->df_err, sizeof(double));
     rc = rc ? rc : alloc_dev(c, (void**)&c->df_part, SPH_DF_ERR_BLOCKS * sizeof(double));
+    rc = rc ? rc : alloc_dev(c, (void**)&c->df_bpart, (size_t)c->brick_cap * sizeof(double));
     if (!rc && hipHostMalloc((void**)&c->h_df_err, sizeof(double), hipHostMallocMapped) != hipSuccess) rc = SPH_E_NOMEM;
     if (!rc && hipHostMalloc((void**)&c->h_df_slot, 4 * sizeof(*c->h_df_slot), hipHostMallocMapped) != hipSuccess) rc = SPH_E_NOMEM;
     rc = rc ? rc : alloc_dev(c, (void**)&c->df_gate, 16);
@@ -256,7 +261,7 @@ int32_t sph_destroy(SphContext* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* ptrs[] = {c->xm[0], c->xm[1], c->vf[0], c->vf[1], c->aux[0], c->aux[1], c->key[0], c->key[1], c->eos, c->stg, c->gat, c->acc,
                     c->acc_tmp, c->cell_buf[0], c->cell_buf[1], c->rank_off, c->idx_unstable, c->scan_status, c->x0_cold, c->color_cold,
-                    c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->acc_fx, c->rigid_part, c->rigid_R, c->df_err, c->df_part, c->stage, c->glist, c->gcnt, c->brick_list, c->brick_count, c->brick_list2, c->brick_count2, c->brick_rec};
+                    c->rigid_rest_cm, c->dyn_list, c->dyn_count, c->acc_fx, c->rigid_part, c->rigid_R, c->df_err, c->df_part, c->df_bpart, c->stage, c->glist, c->gcnt, c->brick_list, c->brick_count, c->brick_list2, c->brick_count2, c->brick_rec};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (int s = 0; s < SPH_MAX_TIMED_STEPS; ++s)
         for (int k = 0; k < 5; ++k) if (c->ev[s][k]) (void)hipEventDestroy(c->ev[s][k]);
@@ -304,6 +309,7 @@ int32_t sph_set_option(SphContext* c, int32_t option, int32_t value) {
             if (value < 0 || value > 2) return sph_fail(c, SPH_E_INVALID, "pure-fluid instance option must be 0, 1 or 2");
             c->opt_pure_instance = value; sph_invalidate_lists(c); return 0;
         case SPH_OPT_BRICK_RECORDS: c->opt_brick_rec = value ? 1 : 0; sph_invalidate_lists(c); return 0;
+        case SPH_OPT_DF_FUSE_ERROR: c->opt_df_fuse_err = value ? 1 : 0; return 0;
     }
     return sph_fail(c, SPH_E_INVALID, "unknown option");
 }
@@ -330,6 +336,7 @@ int32_t sph_get_option(const SphContext* c, int32_t option, int32_t* value) {
         case SPH_OPT_RIGID_SUMS_FROM_X0: *value = c->opt_rigid_x0; return 0;
         case SPH_OPT_PURE_FLUID_INSTANCE: *value = c->opt_pure_instance; return 0;
         case SPH_OPT_BRICK_RECORDS: *value = c->opt_brick_rec; return 0;
+        case SPH_OPT_DF_FUSE_ERROR: *value = c->opt_df_fuse_err; return 0;
     }
     return SPH_E_INVALID;
 }
@@ -1160,7 +1167,11 @@ struct DfSolve { int sweep, refresh; float offset; double eta; int limit; };
 
 static int df_enqueue_body(SphContext* c, const DfSolve& s, int k) {
     int rc = sphk_gather(c, s.sweep);                    // *_solver_iteration(): kernel,
+    // (the refresh sweep also reduces the density error over its own targets, brick by brick, when it runs as a brick sweep)
+    c->df_collect = c->opt_df_fuse_err;
+    c->df_bpart_valid = false;
     rc = rc ? rc : sphk_gather(c, s.refresh);            //   compute_density_change() / compute_density_adv(),
+    c->df_collect = 0;
     rc = rc ? rc : sphk_df_convergence_test(c, s.offset, s.eta, k & 3);  // compute_density_error() + the test
     if (rc) return rc;
     SPH_HIP(c, hipEventRecord(c->ev_df[k & 3], c->stream));

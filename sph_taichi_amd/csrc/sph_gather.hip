@@ -61,6 +61,7 @@ struct Target {
     float dpj_solid;       // p_i / rho0^2 (WCSPH.py:60)
     bool self_in_sum;      // density: the brick path sums the self pair (= m_V_i W(0)) with the neighbours
     int nn;                // DFSPH.py:197 num_neighbors
+    float df_err;          // density-change / -advection finish: this target's term of compute_density_error() (DFSPH.py:224-230), 0 for a non-fluid one
 };
 
 template <int MODE>
@@ -547,19 +548,23 @@ __device__ __forceinline__ void target_finish(const DevView& d, Target& t, int i
         return;
     }
     if (MODE == GM_DF_DENSITY_CHANGE) {  // DFSPH.py:165-180
+        t.df_err = 0.0f;
         if (gathered) {
             float adv = fmaxf(t.s0, 0.0f);
             if (t.nn < 20) adv = 0.0f;
             reinterpret_cast<float*>(&d.eos[i])[1] = adv;
             if (d.write_k) d.kbuf[i] = adv * t.p;  // k_i = b_i * factor_i (DFSPH.py:292-294), for the neighbours
+            t.df_err = fmaf(d.rho0, adv, -0.0f);    // the term k_df_density_error_gated computes from eos.y (offset 0: divergence solve)
         }
         return;
     }
     if (MODE == GM_DF_DENSITY_ADV) {  // DFSPH.py:206-209
+        t.df_err = 0.0f;
         if (gathered) {
             const float adv = fmaxf(t.rho / d.rho0 + d.dt * t.s0, 1.0f);
             reinterpret_cast<float*>(&d.eos[i])[1] = adv;
             if (d.write_k) d.kbuf[i] = (adv - 1.0f) * t.p;  // DFSPH.py:362-363
+            t.df_err = fmaf(d.rho0, adv, -d.rho0);  // ... with the pressure solve's offset density_0 (DFSPH.py:346)
         }
         return;
     }
@@ -948,7 +953,10 @@ __global__ __launch_bounds__(TPB, (brick_waves_per_simd<MODE, VAR>())) void k_ga
     if (mode_is_df_gated<MODE>() && d.gate && gate_word == d.gate_epoch) return;  // (no barrier lies ahead of a workgroup that leaves here)
     const int T = sTOff[64];
     const int total = sColS[64];
-    if (T == 0) return;
+    if (T == 0) {
+        if (mode_is_df_vdiv<MODE>() && d.df_bpart != nullptr && tid == 0) d.df_bpart[bidx] = 0.0;   // (a listed brick without a target of this sweep)
+        return;
+    }
 #ifdef SPH_PROFILE
     if (ts_on && threadIdx.x == 0) d.prof_ts[(size_t)blockIdx.x * 8 + 6] = ((unsigned long long)(unsigned)T << 32) | (unsigned)total;
 #endif
@@ -1037,6 +1045,7 @@ __global__ __launch_bounds__(TPB, (brick_waves_per_simd<MODE, VAR>())) void k_ga
     SPH_TS(2);
 
     // ---- step C: targets ----
+    double df_errsum = 0.0;   // density-change / -advection sweeps inside a solver loop: this lane's share of compute_density_error()
     for (int tn = tid; V_MFMA ? (tn & ~63) < T : tn < T; tn += TPB) {
         const bool valid = !V_MFMA || tn < T;   // V_MFMA: whole waves run the loop (wave-uniform trip count), lanes past T idle
         int col = col_0, gi = gi_0, key_i = key_0;
@@ -1487,8 +1496,26 @@ __global__ __launch_bounds__(TPB, (brick_waves_per_simd<MODE, VAR>())) void k_ga
         }
         SPH_TS(3);
         if (valid) target_finish<MODE, V_EXACT>(d, t, gi, g, Ei);
+        if (mode_is_df_vdiv<MODE>() && d.df_bpart != nullptr) df_errsum += (double)t.df_err;
     }
     SPH_TS(4);
+    // SPH_OPT_DF_FUSE_ERROR (round 6): the iteration's convergence test needs sum over fluid of (density_0 * density_adv - offset); the
+    // values are in registers here, so the brick leaves its partial (f64, fixed order: lane's rounds, wave tree, waves 0..3) and the
+    // streaming kernel that re-read eos + flags of every particle (10.6 us, 7-8 times per step at 1.75 M) is not launched
+    if constexpr (mode_is_df_vdiv<MODE>()) {
+        __shared__ double df_red[TPB / 64];
+        if (d.df_bpart != nullptr) {   // (uniform over the launch)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) df_errsum += __shfl_down(df_errsum, off, 64);
+            if (lane == 0) df_red[wave] = df_errsum;
+            __syncthreads();
+            if (tid == 0) {
+                double tot = 0.0;
+                for (int w = 0; w < TPB / 64; ++w) tot += df_red[w];
+                d.df_bpart[bidx] = tot;
+            }
+        }
+    }
     }
 }
 
@@ -1781,6 +1808,7 @@ static int launch_df(SphContext* c) {
         rc = launch_brick_cfg<MODE, Cfg0>(c);
     }
     if (!rc && mode_writes_list<MODE>()) { c->lists_valid = true; c->gcnt_written = true; c->stg_kind = 2; c->k_kind = 0; }
+    if (!rc && mode_is_df_vdiv<MODE>() && c->df_collect) c->df_bpart_valid = true;   // every listed brick leaves its partial of the density error
     if (!rc && MODE == GM_DF_DENSITY_CHANGE) c->k_kind = 1;
     if (!rc && MODE == GM_DF_DENSITY_ADV) c->k_kind = 2;
     return rc;

@@ -149,6 +149,43 @@ __global__ __launch_bounds__(64) void k_df_convergence_test(const double* __rest
     }
 }
 
+// ... and the same test on the per-BRICK partials the refresh sweep itself left behind (SPH_OPT_DF_FUSE_ERROR: no streaming pass over
+// the particles at all): entries [0, heavy) and (list_cap - light, list_cap) of the brick list, in that order
+__global__ __launch_bounds__(1024) void k_df_convergence_test_bricks(const double* __restrict__ part, const int* __restrict__ brick_count,
+                                                                     int list_cap, int count, double eta,
+                                                                     SphContext::DfSlot* __restrict__ slot, unsigned* __restrict__ gate,
+                                                                     unsigned epoch) {
+    if (*gate == epoch) return;
+    __shared__ double red[16];
+    const int nbh = brick_count[0], n = nbh + brick_count[1];
+    // ONE workgroup adds up ~16 k partials at 1.75 M particles: 1,024 lanes, four independent loads in flight per lane (a
+    // 256-lane loop of dependent adds waited for ~60 loads one after the other: as slow as the streaming kernel it replaced)
+    auto ld = [&](int k) -> double { return k < nbh ? part[k] : part[list_cap - 1 - (k - nbh)]; };
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+    int k = threadIdx.x;
+    for (; k + 3 * 1024 < n; k += 4 * 1024) {
+        const double a = ld(k), b = ld(k + 1024), c = ld(k + 2048), e = ld(k + 3072);
+        v0 += a; v1 += b; v2 += c; v3 += e;
+    }
+    for (; k < n; k += 1024) v0 += ld(k);
+    double v = (v0 + v1) + (v2 + v3);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        const float err = (float)t;                          // compute_density_error returns an f32 (DFSPH.py:224-230)
+        const double avg = (double)err / (double)count;      // Python-scope float arithmetic: f64
+        const int conv = avg <= eta ? 1 : 0;
+        slot->err = err;
+        slot->avg = avg;
+        slot->converged = conv;
+        if (conv) *gate = epoch;
+    }
+}
+
 __global__ __launch_bounds__(64) void k_df_density_error_total(const double* __restrict__ part, int n,
                                                                double* __restrict__ out) {
     double v = 0.0;
@@ -1144,14 +1181,21 @@ int sphk_df_density_error_range(SphContext* c, float offset, int first, int coun
 
 int sphk_df_convergence_test(SphContext* c, float offset, double eta, int slot) {
     DevView d = sph_view(c);
+    SphContext::DfSlot* dev_slot = nullptr;
+    SPH_HIP(c, hipHostGetDevicePointer((void**)&dev_slot, c->h_df_slot, 0));
+    const int count = c->df.fluid_particle_num > 0 ? c->df.fluid_particle_num : 1;
+    if (c->df_bpart_valid) {   // the refresh sweep ran as a brick sweep and left one partial per listed brick (SPH_OPT_DF_FUSE_ERROR)
+        c->df_bpart_valid = false;
+        hipLaunchKernelGGL(k_df_convergence_test_bricks, dim3(1), dim3(1024), 0, c->stream, c->df_bpart, c->brick_count, c->brick_cap, count,
+                           eta, dev_slot + slot, c->df_gate, c->df_epoch);
+        SPH_LAUNCH_CHECK(c);
+        return 0;
+    }
     int nb = (c->N + TPB - 1) / TPB;
     if (nb > SPH_DF_ERR_BLOCKS) nb = SPH_DF_ERR_BLOCKS;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(k_df_density_error_gated, dim3(nb), dim3(TPB), 0, c->stream, d, offset, c->df_part);
     SPH_LAUNCH_CHECK(c);
-    SphContext::DfSlot* dev_slot = nullptr;
-    SPH_HIP(c, hipHostGetDevicePointer((void**)&dev_slot, c->h_df_slot, 0));
-    const int count = c->df.fluid_particle_num > 0 ? c->df.fluid_particle_num : 1;
     hipLaunchKernelGGL(k_df_convergence_test, dim3(1), dim3(64), 0, c->stream, c->df_part, nb, count, eta, dev_slot + slot,
                        c->df_gate, c->df_epoch);
     SPH_LAUNCH_CHECK(c);

@@ -556,6 +556,39 @@ def test_dfsph_solver_loops_running_ahead_of_their_convergence_tests(impl):
     assert np.array_equal(x0, x1) and np.array_equal(v0, v1)
 
 
+@pytest.mark.parametrize("ahead", [0, 1])
+def test_dfsph_density_error_reduced_inside_the_refresh_sweep(ahead):
+    """SPH_OPT_DF_FUSE_ERROR (round 6): inside the solver loops the density-change / -advection sweep of an iteration leaves
+    compute_density_error()'s sum (DFSPH.py:224-230) behind as one f64 partial per brick, and the convergence test adds those up
+    instead of a streaming kernel re-reading every particle.  Same per-particle f32 terms, another f64 grouping: the iteration counts
+    must be the same step by step, the particles bit-identical (the error only decides when a loop ends), the reported average
+    errors equal to f64 round-off -- with the dynamic cube in contact, with and without the loops running ahead."""
+    from sph_taichi_amd import _lib
+    sd = _dfsph_scene()
+    cfg, sc = scenes.build(sd)
+    scenes.jitter(sc, 0.1, seed=5)
+    out = []
+    for fuse in (0, 1):
+        ps, solver = scenes.make_ps(sd, sc.arrays, gather_impl=1)
+        assert ps.get_option(_lib.OPT_DF_FUSE_ERROR) == 1          # the default
+        ps.set_option(_lib.OPT_DF_FUSE_ERROR, fuse)
+        ps.set_option(_lib.OPT_DF_RUNAHEAD, ahead)
+        solver.initialize()
+        its, errs = [], []
+        for _ in range(10):
+            solver.step(1)
+            st = solver.stats()
+            its.append((st["iterations_v"], st["iterations"]))
+            errs.append((st["avg_density_err_v"], st["avg_density_err"]))
+        out.append((its, np.array(errs), scenes.ps_by_pid(ps, "x"), scenes.ps_by_pid(ps, "v")))
+        ps.close()
+    (its0, e0, x0, v0), (its1, e1, x1, v1) = out
+    assert its0 == its1, (its0, its1)
+    assert sum(a for a, _ in its0) > 0, "the divergence solver never iterated: the scene does not test the reduction"
+    assert np.array_equal(x0, x1) and np.array_equal(v0, v1)
+    assert np.all(np.abs(e0 - e1) <= 1e-6 * np.maximum(np.abs(e0), 1e-30)), (e0, e1)   # (the error is an f32 of an f64 sum: one ulp at most)
+
+
 def test_dfsph_reference_step_equals_fast_step_and_stale_lists():
     """(1) SPHBase.step() through the individual DFSPH kernels == sph_dfsph_step(); (2) a list-reading sweep called
     after the particles moved (lists stale) must fall back to the exact cell walk, not read the old lists."""

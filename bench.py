@@ -441,7 +441,11 @@ def main():
                                       "ms_per_step_run_ahead": round(dt_ab1 / args.steps * 1e3, 4),
                                       "same_iteration_counts": bool(same_counts),
                                       "note": "the same W + K steps from the restored initial state with SPH_OPT_DF_RUNAHEAD 1; "
-                                              "host_round_trip_per_iteration = the line's own block (the default)"}},
+                                              "host_round_trip_per_iteration = the line's own block (the default).  The second block starts "
+                                              "from the same positions and velocities in ANOTHER particle order (the one the first block ended in; "
+                                              "the stable sort keeps ties in their previous order), so its f32 sums differ in the last bit and "
+                                              "same_iteration_counts holds only until round-off moves one convergence test (~40 steps at 1.75 M); "
+                                              "bit-identity of the two modes on one order: test_dfsph_solver_loops_running_ahead_of_their_convergence_tests"}},
             "roofline": None,
         }
         # The step is ~37 neighbour sweeps over unchanged positions; all but the first read the neighbour lists.  Algorithmic

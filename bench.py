@@ -268,9 +268,6 @@ def main():
     ap.add_argument("--brick-records", type=int, default=1, choices=[0, 1],
                     help="SPH_OPT_BRICK_RECORDS: 1 (default) = the list-reading sweeps load the brick column tables the density sweep left "
                          "behind, 0 = every sweep recomputes them from the cell array (A/B; bit-identical results)")
-    ap.add_argument("--brick-origin", type=int, default=1, choices=[0, 1],
-                    help="SPH_OPT_BRICK_ORIGIN: 1 (default) = the brick partition's 4 x 2 column groups start at cell 1 (behind the wall padding), "
-                         "0 = at cell 0 (rounds 1-5; A/B)")
     ap.add_argument("--df-fuse-error", type=int, default=1, choices=[0, 1],
                     help="SPH_OPT_DF_FUSE_ERROR (--solver dfsph): 1 (default) = the refresh sweep of a solver iteration reduces the density error "
                          "itself, 0 = a streaming kernel re-reads the particles (A/B)")
@@ -347,7 +344,6 @@ def main():
     solver = ps.build_solver()
     ps.set_option(_lib.OPT_BRICK_RECORDS, args.brick_records)
     ps.set_option(_lib.OPT_DF_FUSE_ERROR, args.df_fuse_error)
-    ps.set_option(_lib.OPT_BRICK_ORIGIN, args.brick_origin)
     N = ps.particle_max_num
     G = int(ps.grid_num[0] * ps.grid_num[1] * ps.grid_num[2])
 
@@ -629,7 +625,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": args.workload, "particles": N, "cells": G, "dt": CFG["timeStepSize"],
                    "gather_impl": args.gather_impl, "brick_shape": args.brick_shape, "fused": args.fused,
-                   "kernel_variant": ps.get_option(_lib.OPT_KERNEL_VARIANT), "brick_records": args.brick_records, "brick_origin": args.brick_origin, "parallelism": "1 GPU",
+                   "kernel_variant": ps.get_option(_lib.OPT_KERNEL_VARIANT), "brick_records": args.brick_records, "parallelism": "1 GPU",
                    "settle_steps": args.settle, "state": "settled" if args.settle else "from rest (steps W..W+K of the initial lattice)"},
         "reps": reps, "timed_seconds": round(t_timed, 3),
         "first_rep": {"value": first["value"], "ms_per_step": first["ms_per_step"]},

@@ -174,12 +174,7 @@ enum SphOption {
                                   / density-advection sweep of an iteration also reduces compute_density_error()'s sum (DFSPH.py:224-230)
                                   over its own targets -- one f64 partial per brick, added up in brick-list order by the convergence
                                   test -- instead of a streaming kernel that re-reads every particle; 0 = that kernel (A/B).  The same
-                                  per-particle f32 terms either way; the f64 grouping differs (both deterministic). */,
-    SPH_OPT_BRICK_ORIGIN = 18 /* 1 (default) = the 4 x 2 column groups of the brick partition start at CELL 1 of x and y (cell 0 lies inside
-                                  the wall padding, particle_system.py:46, so a fluid resting on the floor / against the low walls fills
-                                  whole groups); 0 = they start at cell 0 (rounds 1-5; the A/B).  The partition decides only which
-                                  workgroup handles which target and the order a target's neighbours are summed in: same neighbour
-                                  sets, results within the usual summation-order round-off. */
+                                  per-particle f32 terms either way; the f64 grouping differs (both deterministic). */
 };
 #define SPH_VAR_GROUPS 1   /* density: all nine runs filtered first (masks in registers), hits emitted centre run / edge runs / corner
                               runs, each group by descending hit count */

@@ -57,7 +57,7 @@ F_OBJECT_ID, F_X, F_X_0, F_V, F_ACCELERATION, F_M_V, F_M, F_DENSITY, F_PRESSURE,
 # enum SphOption
 OPT_GATHER_IMPL, OPT_TIMING, OPT_FUSED_STEP, OPT_BRICK_SHAPE, OPT_NO_DYNAMIC_SOLIDS, OPT_DEBUG_ABLATE, \
     OPT_SLAB_DROP_OUTSIDE, OPT_UNIFORM_FLUID, OPT_UNIFORM_FLUID_STATE, OPT_SORT_BY_PID, OPT_KERNEL_VARIANT, \
-    OPT_RIGID_BATCH, OPT_EXACT_MATH, OPT_DF_RUNAHEAD, OPT_RIGID_SUMS_FROM_X0, OPT_PURE_FLUID_INSTANCE, OPT_BRICK_RECORDS, OPT_DF_FUSE_ERROR, OPT_BRICK_ORIGIN = range(19)
+    OPT_RIGID_BATCH, OPT_EXACT_MATH, OPT_DF_RUNAHEAD, OPT_RIGID_SUMS_FROM_X0, OPT_PURE_FLUID_INSTANCE, OPT_BRICK_RECORDS, OPT_DF_FUSE_ERROR = range(18)
 VAR_GROUPS, VAR_GAT_LDS, VAR_GAT_LDS4, VAR_FORCE_BF, VAR_DEEP, VAR_MFMA = 1, 2, 4, 8, 16, 32
 VAR_DEFAULT = VAR_GROUPS | VAR_FORCE_BF | VAR_DEEP
 

@@ -3,7 +3,6 @@
 // sph_step = SPHBase.step() (sph_base.py:263-271) looped on the device.
 #include <sched.h>
 #include "sph_internal.h"
-#include "sph_bricks.h"
 
 #define SCAN_TILE 2048
 
@@ -55,7 +54,6 @@ DevView sph_view(const SphContext* c) {
     d.m_u = c->m_uniform; d.write_sg = 0; d.write_k = 0;
     d.whx = p.wall_hi[0]; d.why = p.wall_hi[1]; d.whz = p.wall_hi[2];
     d.fuse_advect = c->fuse_advect;
-    d.box = c->opt_brick_origin ? SPH_BRICK_OX : 0; d.boy = c->opt_brick_origin ? SPH_BRICK_OY : 0;
     d.df_bpart = c->df_collect ? c->df_bpart : nullptr;
     d.gate = (c->df_epoch && c->opt_df_runahead) ? c->df_gate : nullptr;   // (without run-ahead no body is ever enqueued past convergence)
     d.gate_epoch = c->df_epoch;
@@ -150,7 +148,6 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     c->opt_brick_shape = 0;
     c->opt_rigid_batch = 1;
     c->opt_df_fuse_err = 1;
-    c->opt_brick_origin = 1;
     c->df_collect = 0;
     c->df_bpart_valid = false;
     c->opt_df_runahead = 0;   // measured (r05): running ahead costs 2 % more than the bubbles it removes
@@ -196,7 +193,7 @@ int32_t sph_create(const SphParams* params, int32_t device, void* stream, SphCon
     }
     rc = rc ? rc : alloc_dev(c, (void**)&c->gcnt, cap);
     // bricks have a 4x2-column footprint and a height the list builder chooses (k_brick_list): at worst one per z layer
-    c->brick_cap = SPH_BRICK_NB(params->grid_num[0], SPH_BRICK_OX, SPH_BRICK_BX) * SPH_BRICK_NB(params->grid_num[1], SPH_BRICK_OY, SPH_BRICK_BY) * params->grid_num[2] + 8;   // (sized for either grid origin)
+    c->brick_cap = ((params->grid_num[0] + 3) / 4) * ((params->grid_num[1] + 1) / 2) * params->grid_num[2] + 8;
     rc = rc ? rc : alloc_dev(c, (void**)&c->brick_list, (size_t)c->brick_cap * 8);
     rc = rc ? rc : alloc_dev(c, (void**)&c->brick_count, 16);
     rc = rc ? rc : alloc_dev(c, (void**)&c->brick_rec, (size_t)c->brick_cap * 32 * sizeof(int4));   // 512 B per brick slot
@@ -313,7 +310,6 @@ int32_t sph_set_option(SphContext* c, int32_t option, int32_t value) {
             c->opt_pure_instance = value; sph_invalidate_lists(c); return 0;
         case SPH_OPT_BRICK_RECORDS: c->opt_brick_rec = value ? 1 : 0; sph_invalidate_lists(c); return 0;
         case SPH_OPT_DF_FUSE_ERROR: c->opt_df_fuse_err = value ? 1 : 0; return 0;
-        case SPH_OPT_BRICK_ORIGIN: c->opt_brick_origin = value ? 1 : 0; c->bricks_valid = false; sph_invalidate_lists(c); return 0;
     }
     return sph_fail(c, SPH_E_INVALID, "unknown option");
 }
@@ -341,7 +337,6 @@ int32_t sph_get_option(const SphContext* c, int32_t option, int32_t* value) {
         case SPH_OPT_PURE_FLUID_INSTANCE: *value = c->opt_pure_instance; return 0;
         case SPH_OPT_BRICK_RECORDS: *value = c->opt_brick_rec; return 0;
         case SPH_OPT_DF_FUSE_ERROR: *value = c->opt_df_fuse_err; return 0;
-        case SPH_OPT_BRICK_ORIGIN: *value = c->opt_brick_origin; return 0;
     }
     return SPH_E_INVALID;
 }

@@ -9,23 +9,11 @@
 #define SPH_BRICK_BX 4
 #define SPH_BRICK_BY 2
 #define SPH_BRICK_BZ 4
-// Origin of the brick grid (round 6, SPH_OPT_BRICK_ORIGIN).  Column group (bxi, byi) covers the cells [bxi * BX - ox, ... + BX) x
-// [byi * BY - oy, ... + BY): with ox = BX - 1 and oy = BY - 1 (the default) a group STARTS AT CELL 1.  Cell 0 of every axis lies inside
-// the wall padding (particle_system.py:46: padding = grid_size; enforce_boundary_3D keeps every dynamic particle at >= padding), so a
-// fluid that rests on the floor and against the low walls -- every settled state -- begins in cell 1: groups anchored at 0 paired
-// its first row of cells with an empty one (half-filled bricks along the floor, a quarter missing along the x wall; C1's 64^3
-// lattice made 9 x 17 column groups where 8 x 16 hold it).  Group 0 then holds cell 0 alone (particles there are exceptions:
-// statics, the cell-0 quirk tests).  ox = oy = 0 is the grid of rounds 1-5 (the A/B).
-#define SPH_BRICK_OX (SPH_BRICK_BX - 1)
-#define SPH_BRICK_OY (SPH_BRICK_BY - 1)
-// number of column groups along an axis of n cells with origin offset o_
-#define SPH_BRICK_NB(n_, o_, b_) (((n_) + (o_) + (b_) - 1) / (b_))
 
 // what the builder reads of a context (a whole DevView beside the scatter's own would cost that kernel SGPRs and, with
 // them, resident workgroups)
 struct BrickView {
     int nx, ny, nz;
-    int box, boy;   // origin offset of the brick grid (0 .. BX - 1, 0 .. BY - 1)
     int tgt_lo, tgt_hi, tgt_lo2, tgt_hi2;  // x layers whose particles are targets of the sweeps the list is built for
     const int* cell_end;
 };
@@ -58,7 +46,7 @@ __device__ __forceinline__ void sph_brick_list_block(const BrickView& d, int nbx
     const int cg = block * (SPH_TPB / 64) + wave;
     const bool live = cg < nbx * nby;
     const int bxi = cg / nby, byi = cg % nby;
-    const int cx0 = bxi * BX - d.box, cy0 = byi * BY - d.boy;   // (may be negative: group 0 reaches below cell 0)
+    const int cx0 = bxi * BX, cy0 = byi * BY;
     int carryS = 0, carryT = 0;
     if (live && lane == 0) { Sp[0] = 0; Tp[0] = 0; }
     for (int zb = 0; zb < nz; zb += 64) {

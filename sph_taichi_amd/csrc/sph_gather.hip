@@ -798,7 +798,7 @@ __global__ __launch_bounds__(TPB) void k_brick_list(DevView d, int nbx, int nby,
     extern __shared__ int sm_bl[];
     static_assert(CFG::BX == SPH_BRICK_BX && CFG::BY == SPH_BRICK_BY && CFG::BZ == SPH_BRICK_BZ, "one footprint: the sort's scatter kernel builds the same lists");
     BrickView bv;
-    bv.nx = d.nx; bv.ny = d.ny; bv.nz = d.nz; bv.box = d.box; bv.boy = d.boy; bv.tgt_lo = d.tgt_lo; bv.tgt_hi = d.tgt_hi; bv.tgt_lo2 = d.tgt_lo2; bv.tgt_hi2 = d.tgt_hi2;
+    bv.nx = d.nx; bv.ny = d.ny; bv.nz = d.nz; bv.tgt_lo = d.tgt_lo; bv.tgt_hi = d.tgt_hi; bv.tgt_lo2 = d.tgt_lo2; bv.tgt_hi2 = d.tgt_hi2;
     bv.cell_end = d.cell_end;
     sph_brick_list_block<CFG::BX, CFG::BY, CFG::BZ>(bv, nbx, nby, list, count, list_cap, tmax, smax, fixed_bz, (int)blockIdx.x, sm_bl);
 }
@@ -901,7 +901,7 @@ __global__ __launch_bounds__(TPB, (brick_waves_per_simd<MODE, VAR>())) void k_ga
     // (column group, first z layer | height << 16): the partition of k_brick_list
     const int byi = brick.x % nby;
     const int bxi = brick.x / nby;
-    const int cx0 = bxi * CFG::BX - d.box, cy0 = byi * CFG::BY - d.boy, cz0 = brick.y & 0xffff;   // (sph_bricks.h: by default groups start at cell 1; < 0 in group 0)
+    const int cx0 = bxi * CFG::BX, cy0 = byi * CFG::BY, cz0 = brick.y & 0xffff;
     const int cx1 = min(cx0 + CFG::BX, d.nx), cy1 = min(cy0 + CFG::BY, d.ny), cz1 = min(cz0 + (brick.y >> 16), d.nz);  // excl.
     const int sx0 = max(cx0 - 1, 0), sy0 = max(cy0 - 1, 0), sz0 = max(cz0 - 1, 0);
     const int sx1 = min(cx1, d.nx - 1), sy1 = min(cy1, d.ny - 1), sz1 = min(cz1, d.nz - 1);  // incl.
@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(TPB, (brick_waves_per_simd<MODE, VAR>())) void k_ga
                 const int ix = cx0 + colb / CFG::BY, iy = cy0 + colb % CFG::BY, cz = cz0 + zc;
                 const int nx = ix + r / 3 - 1, ny = iy + r % 3 - 1;
                 unsigned word = 0u;
-                if (ix >= 0 && iy >= 0 && ix < cx1 && iy < cy1 && cz < cz1 && nx >= 0 && nx < d.nx && ny >= 0 && ny < d.ny) {
+                if (ix < cx1 && iy < cy1 && cz < cz1 && nx >= 0 && nx < d.nx && ny >= 0 && ny < d.ny) {
                     const int klo = (cz > 0 ? cz - 1 : 0) - sz0, khi = (cz < d.nz - 1 ? cz + 1 : d.nz - 1) - sz0;
                     const int ncol = (nx - sx0) * ncy + (ny - sy0);
                     const int rel = -sColG[ncol];
@@ -1627,7 +1627,7 @@ static bool brick_ok(const SphContext* c) {
 // identity of a partition: footprint, cut rule, limits (the target ranges complete the key)
 static int brick_partition_id(const SphContext* c) {
     const int fixed_bz = c->opt_brick_shape == 1 ? SPH_BRICK_BZ : 0;
-    return (((SPH_BRICK_BX * 10 + SPH_BRICK_BY) * 10 + SPH_BRICK_BZ) * 2 + (c->opt_brick_origin ? 1 : 0)) * 4096 + fixed_bz * 2048 + brick_smax(c);
+    return ((SPH_BRICK_BX * 10 + SPH_BRICK_BY) * 10 + SPH_BRICK_BZ) * 4096 + fixed_bz * 2048 + brick_smax(c);
 }
 
 // The list for the step's default sweeps (targets = the density layers), to be built by the sort's place kernel in
@@ -1639,10 +1639,9 @@ int sphk_brick_list_prepare(SphContext* c, BrickListArgs* a) {
     DevView d = sph_view(c);
     d.tgt_lo = c->tgt_layers[0]; d.tgt_hi = c->tgt_layers[1]; d.tgt_lo2 = d.tgt_hi2 = 0;
     if (d.tgt_hi <= d.tgt_lo) return 0;
-    const int nbx = SPH_BRICK_NB(d.nx, d.box, SPH_BRICK_BX), nby = SPH_BRICK_NB(d.ny, d.boy, SPH_BRICK_BY);
+    const int nbx = (d.nx + SPH_BRICK_BX - 1) / SPH_BRICK_BX, nby = (d.ny + SPH_BRICK_BY - 1) / SPH_BRICK_BY;
     if (nbx * nby * d.nz > c->brick_cap) return 0;
     a->d.nx = d.nx; a->d.ny = d.ny; a->d.nz = d.nz;
-    a->d.box = d.box; a->d.boy = d.boy;
     a->d.tgt_lo = d.tgt_lo; a->d.tgt_hi = d.tgt_hi; a->d.tgt_lo2 = 0; a->d.tgt_hi2 = 0;
     a->d.cell_end = d.cell_end;
     a->nbx = nbx; a->nby = nby;
@@ -1666,8 +1665,7 @@ static int launch_brick_cfg(SphContext* c, int lo = -1, int hi = -1, int lo2 = 0
     if (d.tgt_hi2 <= d.tgt_lo2) d.tgt_lo2 = d.tgt_hi2 = 0;
     if (d.tgt_hi <= d.tgt_lo) { d.tgt_lo = d.tgt_lo2; d.tgt_hi = d.tgt_hi2; d.tgt_lo2 = d.tgt_hi2 = 0; }
     if (d.tgt_hi <= d.tgt_lo) return 0;
-    static_assert(CFG::BX == SPH_BRICK_BX && CFG::BY == SPH_BRICK_BY, "one footprint and one grid origin (sph_bricks.h)");
-    const int nbx = SPH_BRICK_NB(d.nx, d.box, SPH_BRICK_BX), nby = SPH_BRICK_NB(d.ny, d.boy, SPH_BRICK_BY);
+    const int nbx = (d.nx + CFG::BX - 1) / CFG::BX, nby = (d.ny + CFG::BY - 1) / CFG::BY;
     const int ncg = nbx * nby;          // column groups
     const int nbricks = ncg * d.nz;     // at worst every z layer is a brick of its own
     if (nbricks > c->brick_cap) return sph_fail(c, SPH_E_INVALID, "brick list capacity exceeded");

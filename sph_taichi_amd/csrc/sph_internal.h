@@ -41,7 +41,6 @@ struct DevView {
     int exp_int;     // Tait exponent as a small integer (1..32) when it is one, else 0 (WCSPH.py:76)
     // DFSPH solver loops (round 5): the sweeps of a Jacobi iteration that the host enqueued AHEAD of the previous
     // iteration's convergence test leave at once when that test (made on the device) has closed the solve
-    int box, boy;          // origin offset of the brick grid (sph_bricks.h; SPH_OPT_BRICK_ORIGIN)
     double* df_bpart;      // non-null: the density-change / -advection sweep leaves compute_density_error()'s partial sum of each brick here
     const unsigned* gate;  // null outside the solver loops
     unsigned gate_epoch;   // *gate == gate_epoch: this solve has converged
@@ -174,7 +173,6 @@ struct SphContext {
     int df_collect;     // the sweep being enqueued is such a refresh sweep (sph_view hands df_bpart to the kernel)
     bool df_bpart_valid;  // ... and it went through the brick kernel: the convergence test adds up df_bpart instead of re-reading the particles
     int opt_df_fuse_err;  // SPH_OPT_DF_FUSE_ERROR (default 1)
-    int opt_brick_origin;  // SPH_OPT_BRICK_ORIGIN (default 1: column groups start at cell 1)
     SphDfsphParams df;  // DFSPH solver knobs
     SphDfsphStats df_stats;
     double* df_err;     // device accumulator of compute_density_error

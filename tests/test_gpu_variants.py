@@ -197,53 +197,6 @@ def test_pure_fluid_instance_of_the_density_sweep_is_bit_identical():
         assert np.array_equal(out[0][n], out[1][n]), f"{n} differs between the pure-fluid and the general instance"
 
 
-@pytest.mark.parametrize("scene", ["coupled", "ragged", "cell0"])
-def test_brick_grid_origin_at_cell_0_or_cell_1(scene):
-    """SPH_OPT_BRICK_ORIGIN (round 6): by default the partition's 4 x 2 column groups start at cell 1 (cell 0 is wall padding), 0 = at
-    cell 0 as in rounds 1-5.  The partition only decides which workgroup handles which target and in which order a target's
-    neighbours are summed: both must follow the oracle inside the one-step bounds and agree with each other to summation-order
-    round-off -- on the coupled scene, on the ragged lattice that starts exactly on cell 1's face (the benchmark's initial state),
-    and with fluid that starts INSIDE cell 0 of x and y (group 0 of the shifted grid holds that cell alone)."""
-    from sph_taichi_amd import _lib
-    more = 11
-    if scene == "coupled":
-        sd = scenes.fluid_with_rigid_blocks()
-    elif scene == "ragged":
-        sd = scenes.fluid_only(counts=(18, 14, 16), start=(0.04, 0.04, 0.04), velocity=(0.3, -0.2, 0.1))
-    else:
-        # fluid that STARTS inside the wall padding: targets in cell 0 of x and y for the first sweeps (group 0 of the shifted grid
-        # holds that cell alone; its own lookups meet the reference's max(0, idx - 1) quirk).  The walls throw these particles
-        # back at the first advect -- a violent state nobody bounds -- so this case is held to the ONE-step bounds only.
-        sd = scenes.fluid_only(counts=(12, 10, 9), start=(0.012, 0.012, 0.052), velocity=(0.2, -0.1, 0.1))
-        more = 0
-    cfg, sc = scenes.build(sd)
-    if scene == "coupled":
-        scenes.jitter(sc, 0.1, seed=4)
-    o = scenes.make_oracle(cfg, sc)
-    o.initialize(); o.step(1)
-    ref1 = {n: o.by_pid(n) for n, _ in ONE_STEP_TOL}
-    if more:
-        o.step(more)
-    xref = o.by_pid("x")
-    got = []
-    for origin in (1, 0):
-        ps, solver = scenes.make_ps(sd, sc.arrays)
-        assert ps.get_option(_lib.OPT_BRICK_ORIGIN) == 1          # the default
-        ps.set_option(_lib.OPT_BRICK_ORIGIN, origin)
-        solver.initialize(); solver.step(1)
-        for name, tol in ONE_STEP_TOL:
-            g = scenes.ps_by_pid(ps, name)
-            err = float(np.abs(g.astype(np.float64) - ref1[name]).max()) / max(float(np.abs(ref1[name]).max()), 1e-30)
-            assert err <= tol, (scene, origin, name, err)
-        if more:
-            solver.step(more)
-        x = scenes.ps_by_pid(ps, "x")
-        assert scenes.rel_l2(x, xref) <= 2e-7, (scene, origin)
-        got.append(x)
-        ps.close()
-    assert scenes.rel_l2(got[0], got[1]) <= 2e-7
-
-
 @pytest.mark.parametrize("dfsph", [False, True])
 def test_brick_column_records_change_nothing(dfsph, tmp_path):
     """SPH_OPT_BRICK_RECORDS (round 6): the list-writing density sweep leaves every brick's column tables in HBM and the list

@@ -952,9 +952,12 @@ int32_t sph_slab_advance(SphContext* c, int32_t keep_first, int32_t keep_count, 
     // scatter and the density sweep, 4 us on the stream of every slab step; the host now also gets them a scatter earlier)
     if (!rc && (!layers || n_layers < 0 || n_layers > 16)) rc = SPH_E_INVALID;
     if (!rc) rc = layer_offset_cells(c, layers, n_layers, &c->off_ix);
-    if (!rc) c->off_in_sort = true;
+    if (!rc) { c->off_in_sort = true; c->off_stamp_pending = false; }
     rc = rc ? rc : sort_no_fold(c);
     c->off_in_sort = false;
+    // an EMPTY record set launches no place kernel, so nobody writes the offsets or the stamp: every count below every layer is 0
+    // (sph_layer_offsets_end then neither spins nor reads the mapped words of an earlier step)
+    if (!rc && !c->off_stamp_pending) c->off_zero_mask = 0xffff;
     if (!rc && ev) SPH_HIP(c, hipEventRecord(ev[1], c->stream));
     if (!rc && do_sweeps == 1) rc = sph_sweeps(c);
     if (!rc && do_sweeps == 2) {  // boundary volume + density only; sph_slab_forces does the rest

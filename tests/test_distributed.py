@@ -251,6 +251,29 @@ def test_slab_rank_checkpoint_does_not_trip_over_consumed_accelerations(tmp_path
 
 
 @pytest.mark.gpu
+def test_layer_offsets_of_an_empty_record_set_are_zero():
+    """Since round 6 a slab rank's layer offsets ride in the sort: its place kernel writes them and a stamp into mapped host
+    memory and sph_layer_offsets_end spins on the stamp.  A sort over NO records launches no place kernel: the call must answer
+    with zeros at once -- not spin, and not hand back the mapped words of the step before."""
+    import ctypes as C
+    from sph_taichi_amd.distributed import SlabSolver, run_local_slabs
+    sd = _slab_scenes()[0]
+    solvers = [SlabSolver(sd, r, 2, device=0) for r in range(2)]
+    run_local_slabs(solvers, 0, initialize=True)
+    run_local_slabs(solvers, 2)
+    s = solvers[0]
+    assert s.off[3] > 0                                   # the step before left non-zero counts in the mapped words
+    layers = s._layers()
+    nl = len(layers)
+    s.ps._call("sph_slab_advance", 0, 0, None, 0, None, 0, (C.c_int32 * nl)(*layers), nl, 0)   # keep nothing, receive nothing
+    out = (C.c_int32 * nl)(*([-1] * nl))
+    s.ps._call("sph_layer_offsets_end", out, nl)
+    assert list(out) == [0] * nl
+    for s in solvers:
+        s.close()
+
+
+@pytest.mark.gpu
 def test_interior_accelerations_are_refused_while_they_are_not_materialised():
     """in slab mode the interior force sweep integrates its targets in its finish and does not write their
     accelerations out; a download used to return stale values silently.  Now it fails with a message, and a stand-alone

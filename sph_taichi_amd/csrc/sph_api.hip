@@ -823,9 +823,12 @@ int32_t sph_layer_offsets_end(SphContext* c, int32_t* out, int32_t n) {
             // (several ranks may share the host's cores -- the one-GPU tests run 2-3 of them: past the first few microseconds a
             // waiting rank gives its core away instead of burning it)
             if (spins > 4096) sched_yield();
-            if ((spins & 0xffff) == 0 && hipStreamQuery(c->stream) == hipSuccess &&
-                __atomic_load_n(&hp[17], __ATOMIC_ACQUIRE) != c->off_stamp)
-                return sph_fail(c, SPH_E_STATE, "sph_layer_offsets_end: the sort finished without delivering the layer offsets");
+            if ((spins & 0xffff) == 0) {
+                const hipError_t q = hipStreamQuery(c->stream);
+                if (q == hipSuccess && __atomic_load_n(&hp[17], __ATOMIC_ACQUIRE) != c->off_stamp)
+                    return sph_fail(c, SPH_E_STATE, "sph_layer_offsets_end: the sort finished without delivering the layer offsets");
+                if (q != hipSuccess && q != hipErrorNotReady) SPH_HIP(c, q);   // a failed launch / device fault: the stamp will never come
+            }
         }
     } else {
         SPH_HIP(c, hipEventSynchronize(c->ev_off));
@@ -948,8 +951,9 @@ int32_t sph_slab_advance(SphContext* c, int32_t keep_first, int32_t keep_count, 
     rc = rc ? rc : sph_append_records(c, srcL, nL);
     rc = rc ? rc : sph_append_records(c, srcR, nR);
     // the layer offsets ride in the sort: its place kernel -- the first kernel behind the scan -- copies the scanned cells into
-    // the mapped buffer and ev_off is recorded right behind it (r06: k_read_cells was a launch of its own between the
-    // scatter and the density sweep, 4 us on the stream of every slab step; the host now also gets them a scatter earlier)
+    // the mapped buffer and writes the sort's stamp behind them, which sph_layer_offsets_end spins on (r06: k_read_cells was a
+    // launch of its own between the scatter and the density sweep and an event record behind it, ~8 us on the stream of every
+    // slab step; the host now also gets the offsets a scatter earlier)
     if (!rc && (!layers || n_layers < 0 || n_layers > 16)) rc = SPH_E_INVALID;
     if (!rc) rc = layer_offset_cells(c, layers, n_layers, &c->off_ix);
     if (!rc) { c->off_in_sort = true; c->off_stamp_pending = false; }
